@@ -1,0 +1,168 @@
+/*
+ * fdwave.h -- C ABI of libfdwave.so: the MI355X (gfx950) implementation of the 2-D acoustic
+ * finite-difference hot path of FernandoSchett/parallel_finite_difference_computation.
+ *
+ * Plain C: pointers, ints, floats.  No HIP or torch types cross this boundary (a stream is a void*
+ * that is really a hipStream_t; NULL = the context's own stream).  Every function returns 0 on
+ * success or a negative FDW_E* code, with a human-readable message in fdw_last_error().  There is
+ * NO CPU fallback: without a usable HIP device fdw_create() fails with FDW_ENODEVICE.
+ *
+ * Each entry point cites the reference interface it replaces.  File tags:
+ *   S = cuda_reference_stencil_computation/fd-source-code.cu
+ *   R = cuda_reference_RTM/src/fd-code.cu
+ *   H = cuda_reference_RTM/lib/include/functions.h
+ *   F = cuda_reference_RTM/lib/src/functions.c
+ *
+ * Array conventions are the reference's: a field is float[nxe][nze], x slow, z contiguous
+ * (idx = ix*nze + iz, R:58), fp32 little endian, nxe = nx + 2*nxb, nze = nz + 2*nzb (R:410-411).
+ * "Host" arrays are dense with that layout.  "Device" arrays (fdw_dev_*) are pitched:
+ * float[nxl][pitch] with pitch = fdw_pitch(ctx) >= nze, padding columns must be zero.
+ */
+#ifndef FDWAVE_H
+#define FDWAVE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDW_VERSION 1
+#define FDW_MAX_ORDER 32
+
+/* error codes */
+#define FDW_OK 0
+#define FDW_EINVAL (-1)    /* bad argument (message says which) */
+#define FDW_ENODEVICE (-2) /* no HIP device / wrong architecture / HIP runtime failure at create */
+#define FDW_EHIP (-3)      /* a HIP call failed later */
+#define FDW_ENOMEM (-4)
+#define FDW_ESTATE (-5)    /* call sequence error (e.g. back() before forward() in a device-resident shot) */
+
+typedef struct fdw_ctx fdw_ctx;
+
+/* The arguments of the reference's fd_init (R:200, H:15; stencil variant S:241) plus the switches
+ * that the reference fixes at build time. */
+typedef struct fdw_params {
+    int order;      /* even, 2..FDW_MAX_ORDER (R:374 default 8).  2/4/6/8 use the register-window kernel */
+    int nxe, nze;   /* extended grid (R:410-411) */
+    int nxb, nzb;   /* absorbing border widths (R:375-376); 0 allowed (stencil program does not use them) */
+    int nt;         /* time steps per propagation (R:351) */
+    float dx, dz, dt;
+    float fac;      /* taper strength F (R:377), in (0,1] */
+    int compat;     /* 1: reproduce the reference's truncated RTM launch extents, gridx = floor(nxe/8)
+                       etc. (R:185-195) -- required for parity with rtm_code output;
+                       0: update the whole array */
+    int coef_cxx;   /* 1: generic-order weights with float cosf/powf as in the stencil program (S:184-216
+                       is compiled as C++); 0: double libm as in libsource.a (F:160-192).  Irrelevant
+                       for order 2/4/6/8 */
+} fdw_params;
+
+/* A slab of the global grid owned by one device (domain decomposition along x, the slow axis).
+ * The reference has no multi-GPU path; slab 0..nxe is the single-GPU case. */
+typedef struct fdw_slab {
+    int x_off; /* global row index of local row 0 (may include ghost rows) */
+    int nxl;   /* local rows held on this device, ghost rows included */
+} fdw_slab;
+
+const char *fdw_last_error(void);
+int fdw_version(void);
+
+/* ---- life cycle ------------------------------------------------------------------------------
+ * fdw_create       replaces fd_init + fd_init_cuda (R:146-224, S:218-262): derived constants
+ *                  (d?2inv, dt2, scaled coefficients, taper tables), device buffers, launch
+ *                  geometry.  device = HIP ordinal.
+ * fdw_create_slab  same for one x-slab of a decomposed grid; slab rows must hold order/2 ghost
+ *                  rows (or more) towards every neighbouring slab.
+ * fdw_destroy      replaces the cudaFree block R:569-582 / S:264-275. */
+int fdw_create(const fdw_params *prm, int device, fdw_ctx **out);
+int fdw_create_slab(const fdw_params *prm, const fdw_slab *slab, int device, fdw_ctx **out);
+void fdw_destroy(fdw_ctx *ctx);
+
+/* ---- host-array entry points (the reference's L2 seam; synchronous like the reference) ---------
+ *
+ * fdw_laplacian   S:320-333: H2D(p), kernel_lap, D2H(lap).  lap border cells are written as 0
+ *                 (the committed golden has zeros there).  Uses coef_cxx weights.
+ *
+ * fdw_forward     fd_forward R:247-288.  p,pp in/out (the reference uploads them R:230-231 and
+ *                 downloads d_p,d_pp R:285-286); v2 = squared velocity; sx,sz = source position on
+ *                 the extended grid (R:406,408); srce[nsteps]; nsteps normally = nt.
+ *
+ * fdw_back        fd_back R:290-341.  snap0 = P and snap1 = PP of the forward pass (R:502-507),
+ *                 d_obs = one shot gather [nx][nt] (R:426-435), gz on the extended grid (R:409),
+ *                 imloc[nx][nz] in/out (uploaded R:243, downloaded R:340).
+ *
+ * fdw_shot        forward + back for one shot with everything device-resident (no snapshot round
+ *                 trip): what main does per shot R:496-518 minus the host memsets.  Results are
+ *                 identical to fdw_forward followed by fdw_back.  P/PP may be NULL.
+ */
+int fdw_laplacian(fdw_ctx *ctx, const float *p, float *lap);
+int fdw_forward(fdw_ctx *ctx, float *p, float *pp, const float *v2, int sx, int sz, const float *srce, int nsteps);
+int fdw_back(fdw_ctx *ctx, const float *v2, const float *snap0, const float *snap1, const float *d_obs, int gz,
+             float *imloc, int nsteps);
+int fdw_shot(fdw_ctx *ctx, const float *v2, int sx, int sz, int gz, const float *srce, const float *d_obs,
+             float *imloc, float *P, float *PP);
+
+/* ---- device-array entry points (benchmarks, multi-GPU drivers; asynchronous on `stream`) -------
+ * Buffers are caller-owned device memory laid out [nxl][fdw_pitch()] (e.g. a torch tensor).
+ *
+ * fdw_dev_step    one fused time step on rows [r0,r1) of the slab:
+ *                   mode 0 FWD   taper + Laplacian + leap-frog + point source  (R:264-267)
+ *                   mode 1 PLAIN Laplacian + leap-frog                          (R:317-318)
+ *                   mode 2 RECV  taper + Laplacian + leap-frog + receivers + imaging (R:325-329)
+ *                 d_p is read, d_pp is read and overwritten with the new field (the caller swaps
+ *                 roles afterwards, R:260-262).  pp_twice: 0 on the first step after fresh data,
+ *                 1 afterwards (see fdw_kernels.hip "lazy taper").  d_inj: FWD: device pointer to
+ *                 the source sample of this step, inj_x/inj_z its GLOBAL position (inj_x < 0: no
+ *                 source); RECV: device pointer to nx receiver samples of this step (row-contiguous,
+ *                 i.e. d_obs transposed to [it][ix]), inj_z = gz.  d_psrc/d_img: RECV only.
+ * fdw_dev_taper_finalize  applies the one taper pass the lazy scheme still owes to a field that was
+ *                 last used as d_p (needed before it is exported or used untapered).
+ * fdw_dev_laplacian  mode 3: d_lap = Laplacian(d_p), zero outside the interior.
+ * fdw_dev_steps   nsteps FWD steps with internal role swapping; *d_srce is srce[] on the device
+ *                 (may be NULL = no source).  After an odd number of steps the newest field is in
+ *                 the buffer passed as d_pp, after an even number in d_p (as in the reference loop).
+ */
+int fdw_pitch(const fdw_ctx *ctx);           /* floats per row of a device array */
+size_t fdw_field_bytes(const fdw_ctx *ctx);  /* nxl * pitch * 4 */
+int fdw_dev_step(fdw_ctx *ctx, int mode, const float *d_p, float *d_pp, const float *d_v2, int r0, int r1,
+                 int pp_twice, const float *d_inj, int inj_x, int inj_z, const float *d_psrc, float *d_img,
+                 void *stream);
+int fdw_dev_steps(fdw_ctx *ctx, float *d_p, float *d_pp, const float *d_v2, const float *d_srce, int sx, int sz,
+                  int it0, int nsteps, int first_pp_twice, void *stream);
+int fdw_dev_taper_finalize(fdw_ctx *ctx, float *d_f, void *stream);
+int fdw_dev_laplacian(fdw_ctx *ctx, const float *d_p, float *d_lap, void *stream);
+
+/* host <-> pitched device copies (dense [rows][nze] on the host side), synchronous */
+int fdw_upload_field(fdw_ctx *ctx, float *d_dst, const float *h_src);
+int fdw_download_field(fdw_ctx *ctx, float *h_dst, const float *d_src);
+
+/* ---- tuning / introspection --------------------------------------------------------------------
+ * fdw_set_tuning  xchunk = rows marched per wave (0 = auto), wz = waves of a block laid along z
+ *                 (1,2,4; 0 = auto), use_generic = force the generic-order kernel (tests).
+ * fdw_get_tables  copies of the derived host tables (any pointer may be NULL):
+ *                 coefs_x/z[order+1] (R:214-217), taper_x[nxb], taper_z[nzb] (R:159-166).
+ * fdw_get_extents xlim/zlim = rows/columns the time update covers, ztap = damped columns (R:185-195).
+ * fdw_selftest    runs the DPP wave-shift self test on the device; 0 if the hardware behaves as the
+ *                 step kernel assumes.
+ */
+int fdw_set_tuning(fdw_ctx *ctx, int xchunk, int wz, int use_generic);
+int fdw_get_tables(const fdw_ctx *ctx, float *coefs_x, float *coefs_z, float *taper_x, float *taper_z);
+int fdw_get_extents(const fdw_ctx *ctx, int *xlim, int *zlim, int *ztap);
+int fdw_selftest(fdw_ctx *ctx);
+
+/* ---- host formulas of libsource.a restated (pure C, usable without a device) --------------------
+ * fdw_calc_coefs        calc_coefs + makeo2, F:113-192 / S:137-216 (cxx selects the float variant)
+ * fdw_ricker_wavelet    ricker_wavelet, F:302-334
+ * fdw_taper_tables      taper tables of fd_init_cuda, R:159-166
+ * fdw_extendvel_linear  extendvel_linear, F:336-394; vel is [nxe][nze] contiguous; draws from glibc
+ *                       rand() in the reference's order (unseeded in the reference, R:486)
+ */
+int fdw_calc_coefs(int order, int cxx, float *coef /* [order+1] */);
+void fdw_ricker_wavelet(int nt, float dt, float fpeak, float *s);
+void fdw_taper_tables(int nxb, int nzb, float fac, float *taper_x, float *taper_z);
+void fdw_extendvel_linear(int nx, int nz, int nxb, int nzb, float *vel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDWAVE_H */

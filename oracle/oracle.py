@@ -1,0 +1,139 @@
+"""ctypes front end of the CPU oracle (oracle/fdw_oracle.c) -- TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the
+product package.  Builds liborc.so on first use (gcc -O2 -ffp-contract=off, oracle/Makefile).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liborc.so")
+        src = os.path.join(_HERE, "fdw_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            build()
+        L = C.CDLL(so)
+        L.orc_calc_coefs.argtypes = [C.c_int, C.c_int, f32p]
+        L.orc_scaled_coefs.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, f32p, f32p]
+        L.orc_taper_tables.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
+        L.orc_ricker_wavelet.argtypes = [C.c_int, C.c_float, C.c_float, f32p]
+        L.orc_extendvel_linear.argtypes = [C.c_int] * 4 + [f32p]
+        L.orc_srand.argtypes = [C.c_uint]
+        L.orc_extents.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)] * 3
+        L.orc_init.restype = C.c_void_p
+        L.orc_init.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [C.c_int]
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_fd_forward.argtypes = [C.c_void_p, f32p, f32p, f32p, C.c_int, C.c_int, f32p, C.c_int]
+        L.orc_fd_back.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, f32p, C.c_int]
+        L.orc_stencil.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f32p, f32p]
+        L.orc_fused_steps.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, C.c_float, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def ref_lib():
+    """The reference's own functions.c compiled unmodified (oracle/_ref); None when not built."""
+    so = os.path.join(_HERE, "_ref", "libref_functions.so")
+    if not os.path.exists(so):
+        return None
+    L = C.CDLL(so)
+    L.calc_coefs.restype = C.POINTER(C.c_float)
+    L.calc_coefs.argtypes = [C.c_int]
+    L.ricker_wavelet.argtypes = [C.c_int, C.c_float, C.c_float, f32p]
+    L.extendvel_linear.argtypes = [C.c_int] * 4 + [C.POINTER(C.POINTER(C.c_float))]
+    return L
+
+
+def calc_coefs(order, cxx=False):
+    c = np.zeros(order + 1, np.float32)
+    lib().orc_calc_coefs(order, int(cxx), c)
+    return c
+
+
+def scaled_coefs(order, dx, dz, cxx=False):
+    cx = np.zeros(order + 1, np.float32)
+    cz = np.zeros(order + 1, np.float32)
+    lib().orc_scaled_coefs(order, dx, dz, int(cxx), cx, cz)
+    return cx, cz
+
+
+def taper_tables(nxb, nzb, fac):
+    tx = np.zeros(max(nxb, 1), np.float32)
+    tz = np.zeros(max(nzb, 1), np.float32)
+    lib().orc_taper_tables(nxb, nzb, fac, tx, tz)
+    return tx[:nxb], tz[:nzb]
+
+
+def ricker_wavelet(nt, dt, fpeak):
+    s = np.zeros(nt, np.float32)
+    lib().orc_ricker_wavelet(nt, dt, fpeak, s)
+    return s
+
+
+def extendvel_linear(vpe, nx, nz, nxb, nzb, seed=None):
+    """In place on vpe[nxe][nze].  seed=None keeps the process's current glibc rand() state."""
+    assert vpe.shape == (nx + 2 * nxb, nz + 2 * nzb) and vpe.dtype == np.float32
+    if seed is not None:
+        lib().orc_srand(seed)
+    lib().orc_extendvel_linear(nx, nz, nxb, nzb, vpe)
+    return vpe
+
+
+def extents(nxe, nze, nzb, compat):
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    lib().orc_extents(nxe, nze, nzb, int(compat), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def stencil(order, nxe, nze, dx, dz, field):
+    out = np.zeros((nxe, nze), np.float32)
+    lib().orc_stencil(order, nxe, nze, dx, dz, np.ascontiguousarray(field, np.float32).reshape(nxe, nze), out)
+    return out
+
+
+class Oracle:
+    """State of one reference fd_init (R:200-224) on the CPU."""
+
+    def __init__(self, order, nxe, nze, nxb, nzb, nt, fac, dx, dz, dt, compat=True):
+        self.shape = (nxe, nze)
+        self.nx, self.nz, self.nt = nxe - 2 * nxb, nze - 2 * nzb, nt
+        self._h = lib().orc_init(order, nxe, nze, nxb, nzb, nt, fac, dx, dz, dt, int(compat))
+        if not self._h:
+            raise ValueError("orc_init rejected the parameters")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_free(self._h)
+            self._h = None
+
+    def forward(self, v2, sx, sz, srce, p=None, pp=None, nsteps=None):
+        """R:247-288.  Returns (P, PP) = (d_p, d_pp) after nsteps iterations."""
+        p = np.zeros(self.shape, np.float32) if p is None else np.array(p, np.float32, order="C")
+        pp = np.zeros(self.shape, np.float32) if pp is None else np.array(pp, np.float32, order="C")
+        nsteps = len(srce) if nsteps is None else nsteps
+        lib().orc_fd_forward(self._h, p, pp, np.ascontiguousarray(v2, np.float32), sx, sz,
+                             np.ascontiguousarray(srce, np.float32), nsteps)
+        return p, pp
+
+    def back(self, v2, snap0, snap1, d_obs, gz, imloc=None, nsteps=None):
+        """R:290-341.  d_obs is [nx][nt]; returns imloc [nx][nz]."""
+        imloc = np.zeros((self.nx, self.nz), np.float32) if imloc is None else np.array(imloc, np.float32, order="C")
+        nsteps = self.nt if nsteps is None else nsteps
+        d_obs = np.ascontiguousarray(d_obs, np.float32)
+        assert d_obs.shape == (self.nx, self.nt)
+        lib().orc_fd_back(self._h, np.ascontiguousarray(v2, np.float32), np.ascontiguousarray(snap0, np.float32),
+                          np.ascontiguousarray(snap1, np.float32), d_obs, gz, imloc, nsteps)
+        return imloc

@@ -1,0 +1,11 @@
+"""parallel_finite_difference_computation_amd -- MI355X (gfx950) 2-D acoustic finite-difference /
+RTM hot path behind the reference's own interfaces.  The compute lives in libfdwave.so
+(csrc/: hand-written HIP kernels + C ABI, include/fdwave.h); this package is the thin host side.
+Importing the package does not touch the GPU; using it without libfdwave.so raises ImportError.
+"""
+from ._lib import FdwError, LIB_PATH, MODE_FWD, MODE_PLAIN, MODE_RECV, lib  # noqa: F401
+from .api import (FDWave, calc_coefs, extendvel_linear, fd_back, fd_forward, fd_init, ricker_wavelet,  # noqa: F401
+                  taper_tables)
+
+__all__ = ["FDWave", "FdwError", "calc_coefs", "ricker_wavelet", "taper_tables", "extendvel_linear",
+           "fd_init", "fd_forward", "fd_back", "lib", "LIB_PATH", "MODE_FWD", "MODE_PLAIN", "MODE_RECV"]

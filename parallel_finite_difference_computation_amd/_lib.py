@@ -1,0 +1,85 @@
+"""ctypes binding of libfdwave.so (include/fdwave.h).  No fallback: a missing library is an error."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfdwave.so")
+
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+vp = C.c_void_p
+
+FDW_OK, FDW_EINVAL, FDW_ENODEVICE, FDW_EHIP, FDW_ENOMEM, FDW_ESTATE = 0, -1, -2, -3, -4, -5
+MODE_FWD, MODE_PLAIN, MODE_RECV = 0, 1, 2
+
+
+class FdwError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libfdwave error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    """struct fdw_params (fdwave.h) == the arguments of the reference's fd_init (fd-code.cu:200)."""
+    _fields_ = [("order", C.c_int), ("nxe", C.c_int), ("nze", C.c_int), ("nxb", C.c_int), ("nzb", C.c_int),
+                ("nt", C.c_int), ("dx", C.c_float), ("dz", C.c_float), ("dt", C.c_float), ("fac", C.c_float),
+                ("compat", C.c_int), ("coef_cxx", C.c_int)]
+
+
+class Slab(C.Structure):
+    _fields_ = [("x_off", C.c_int), ("nxl", C.c_int)]
+
+
+# every symbol fdwave.h declares: (name, restype, argtypes)
+SIGNATURES = [
+    ("fdw_last_error", C.c_char_p, []),
+    ("fdw_version", C.c_int, []),
+    ("fdw_create", C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(vp)]),
+    ("fdw_create_slab", C.c_int, [C.POINTER(Params), C.POINTER(Slab), C.c_int, C.POINTER(vp)]),
+    ("fdw_destroy", None, [vp]),
+    ("fdw_laplacian", C.c_int, [vp, f32p, f32p]),
+    ("fdw_forward", C.c_int, [vp, f32p, f32p, f32p, C.c_int, C.c_int, f32p, C.c_int]),
+    ("fdw_back", C.c_int, [vp, f32p, f32p, f32p, f32p, C.c_int, f32p, C.c_int]),
+    ("fdw_shot", C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, vp, vp]),
+    ("fdw_pitch", C.c_int, [vp]),
+    ("fdw_field_bytes", C.c_size_t, [vp]),
+    ("fdw_dev_step", C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),
+    ("fdw_dev_steps", C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    ("fdw_dev_taper_finalize", C.c_int, [vp, vp, vp]),
+    ("fdw_dev_laplacian", C.c_int, [vp, vp, vp, vp]),
+    ("fdw_upload_field", C.c_int, [vp, vp, f32p]),
+    ("fdw_download_field", C.c_int, [vp, f32p, vp]),
+    ("fdw_set_tuning", C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+    ("fdw_get_tables", C.c_int, [vp, vp, vp, vp, vp]),
+    ("fdw_get_extents", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("fdw_selftest", C.c_int, [vp]),
+    ("fdw_calc_coefs", C.c_int, [C.c_int, C.c_int, f32p]),
+    ("fdw_ricker_wavelet", None, [C.c_int, C.c_float, C.c_float, f32p]),
+    ("fdw_taper_tables", None, [C.c_int, C.c_int, C.c_float, vp, vp]),
+    ("fdw_extendvel_linear", None, [C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load libfdwave.so.  Raises (never falls back) if it has not been built: run
+    `python -c 'import __graft_entry__ as g; g.build()'` or `make -C parallel_finite_difference_computation_amd/csrc`."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                              "(hipcc, gfx950).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, res, args in SIGNATURES:
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise FdwError(rc, lib().fdw_last_error().decode(errors="replace"))

@@ -1,0 +1,196 @@
+"""Host-side mirror of the reference's propagation API on top of libfdwave.so.
+
+The reference (cuda_reference_RTM/src/fd-code.cu) exposes fd_init / fd_forward / fd_back as C
+functions over file-scope globals; `FDWave` is that state as an object and keeps the reference's
+argument meaning (extended-grid sizes, nz-before-nx order of the raw arrays, sx/sz/gz on the
+extended grid).  All arrays are numpy float32 [nxe][nze] (x slow, z contiguous, fd-code.cu:58).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Params, Slab, check, lib
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+# ---- host formulas (functions.c restated in csrc/fdw_host.c) --------------------------------------
+def calc_coefs(order, cxx=False):
+    """calc_coefs (functions.c:113-158); cxx=True = the stencil program's float-overload variant."""
+    c = np.zeros(order + 1, np.float32)
+    check(lib().fdw_calc_coefs(order, int(cxx), c))
+    return c
+
+
+def ricker_wavelet(nt, dt, fpeak):
+    """ricker_wavelet (functions.c:328-334)."""
+    s = np.zeros(nt, np.float32)
+    lib().fdw_ricker_wavelet(nt, dt, fpeak, s)
+    return s
+
+
+def taper_tables(nxb, nzb, fac):
+    """taper_x / taper_z of fd_init_cuda (fd-code.cu:159-166)."""
+    tx = np.zeros(max(nxb, 1), np.float32)
+    tz = np.zeros(max(nzb, 1), np.float32)
+    lib().fdw_taper_tables(nxb, nzb, fac, tx.ctypes.data, tz.ctypes.data)
+    return tx[:nxb], tz[:nzb]
+
+
+def extendvel_linear(vpe, nx, nz, nxb, nzb):
+    """extendvel_linear (functions.c:336-394), in place; draws from glibc rand()."""
+    if vpe.shape != (nx + 2 * nxb, nz + 2 * nzb) or vpe.dtype != np.float32 or not vpe.flags.c_contiguous:
+        raise ValueError("vpe must be C-contiguous float32 [nx+2nxb][nz+2nzb]")
+    lib().fdw_extendvel_linear(nx, nz, nxb, nzb, vpe)
+    return vpe
+
+
+class FDWave:
+    """One fd_init (fd-code.cu:200-224 / fd-source-code.cu:241-262) worth of state on one MI355X."""
+
+    def __init__(self, order, nxe, nze, nxb=0, nzb=0, nt=0, fac=1.0, dx=1.0, dz=1.0, dt=0.0, *, compat=True,
+                 coef_cxx=False, device=0, slab=None):
+        self.params = Params(order, nxe, nze, nxb, nzb, nt, dx, dz, dt, fac, int(compat), int(coef_cxx))
+        self._h = C.c_void_p()
+        if slab is None:
+            check(lib().fdw_create(C.byref(self.params), device, C.byref(self._h)))
+            self.x_off, self.nxl = 0, nxe
+        else:
+            self.x_off, self.nxl = slab
+            s = Slab(self.x_off, self.nxl)
+            check(lib().fdw_create_slab(C.byref(self.params), C.byref(s), device, C.byref(self._h)))
+        self.order, self.nxe, self.nze, self.nxb, self.nzb, self.nt = order, nxe, nze, nxb, nzb, nt
+        self.nx, self.nz = nxe - 2 * nxb, nze - 2 * nzb
+        self.device = device
+        self.pitch = lib().fdw_pitch(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().fdw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- introspection --------------------------------------------------------------------------
+    def tables(self):
+        cx = np.zeros(self.order + 1, np.float32)
+        cz = np.zeros(self.order + 1, np.float32)
+        tx = np.zeros(max(self.nxb, 1), np.float32)
+        tz = np.zeros(max(self.nzb, 1), np.float32)
+        check(lib().fdw_get_tables(self._h, cx.ctypes.data, cz.ctypes.data, tx.ctypes.data, tz.ctypes.data))
+        return cx, cz, tx[:self.nxb], tz[:self.nzb]
+
+    def extents(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(lib().fdw_get_extents(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def set_tuning(self, xchunk=0, wz=0, use_generic=False):
+        check(lib().fdw_set_tuning(self._h, xchunk, wz, int(use_generic)))
+
+    def selftest(self):
+        check(lib().fdw_selftest(self._h))
+
+    # ---- host-array API (the reference's L2 seam) -----------------------------------------------
+    def laplacian(self, p):
+        """stencil_code's single kernel_lap launch (fd-source-code.cu:320-333)."""
+        p = _f32(p, (self.nxe, self.nze))
+        out = np.empty_like(p)
+        check(lib().fdw_laplacian(self._h, p, out))
+        return out
+
+    def forward(self, v2, sx, sz, srce, p=None, pp=None, nsteps=None):
+        """fd_forward (fd-code.cu:247-288): returns (P, PP) = (d_p, d_pp) after the loop."""
+        shape = (self.nxe, self.nze)
+        p = np.zeros(shape, np.float32) if p is None else np.array(p, np.float32, order="C")
+        pp = np.zeros(shape, np.float32) if pp is None else np.array(pp, np.float32, order="C")
+        srce = _f32(srce)
+        nsteps = len(srce) if nsteps is None else nsteps
+        if nsteps > len(srce):
+            raise ValueError("srce shorter than nsteps")
+        check(lib().fdw_forward(self._h, p, pp, _f32(v2, shape), sx, sz, srce, nsteps))
+        return p, pp
+
+    def back(self, v2, snap0, snap1, d_obs, gz, imloc=None, nsteps=None):
+        """fd_back (fd-code.cu:290-341): d_obs [nx][nt]; returns imloc [nx][nz]."""
+        shape = (self.nxe, self.nze)
+        imloc = np.zeros((self.nx, self.nz), np.float32) if imloc is None else np.array(imloc, np.float32, order="C")
+        nsteps = self.nt if nsteps is None else nsteps
+        check(lib().fdw_back(self._h, _f32(v2, shape), _f32(snap0, shape), _f32(snap1, shape),
+                             _f32(d_obs, (self.nx, self.nt)), gz, imloc, nsteps))
+        return imloc
+
+    def shot(self, v2, sx, sz, gz, srce, d_obs, imloc=None, want_fields=False):
+        """One shot of rtm_code's loop (fd-code.cu:496-518), device resident."""
+        shape = (self.nxe, self.nze)
+        imloc = np.zeros((self.nx, self.nz), np.float32) if imloc is None else np.array(imloc, np.float32, order="C")
+        P = np.zeros(shape, np.float32) if want_fields else None
+        PP = np.zeros(shape, np.float32) if want_fields else None
+        check(lib().fdw_shot(self._h, _f32(v2, shape), sx, sz, gz, _f32(srce, (self.nt,)),
+                             _f32(d_obs, (self.nx, self.nt)), imloc,
+                             P.ctypes.data if want_fields else None, PP.ctypes.data if want_fields else None))
+        return (imloc, P, PP) if want_fields else imloc
+
+    # ---- device-array API (raw pointers; see device.py for torch helpers) -----------------------
+    def dev_step(self, mode, d_p, d_pp, d_v2, r0=0, r1=None, pp_twice=True, d_inj=None, inj_x=-1, inj_z=0,
+                 d_psrc=None, d_img=None, stream=None):
+        r1 = self.nxl if r1 is None else r1
+        check(lib().fdw_dev_step(self._h, mode, d_p, d_pp, d_v2, r0, r1, int(pp_twice), d_inj, inj_x, inj_z,
+                                 d_psrc, d_img, stream))
+
+    def dev_steps(self, d_p, d_pp, d_v2, d_srce, sx, sz, it0, nsteps, first_pp_twice=False, stream=None):
+        check(lib().fdw_dev_steps(self._h, d_p, d_pp, d_v2, d_srce, sx, sz, it0, nsteps, int(first_pp_twice), stream))
+
+    def dev_taper_finalize(self, d_f, stream=None):
+        check(lib().fdw_dev_taper_finalize(self._h, d_f, stream))
+
+    def dev_laplacian(self, d_p, d_lap, stream=None):
+        check(lib().fdw_dev_laplacian(self._h, d_p, d_lap, stream))
+
+    def upload(self, d_dst, h_src):
+        check(lib().fdw_upload_field(self._h, d_dst, _f32(h_src, (self.nxl, self.nze))))
+
+    def download(self, d_src):
+        out = np.empty((self.nxl, self.nze), np.float32)
+        check(lib().fdw_download_field(self._h, out, d_src))
+        return out
+
+
+# ---- literal reference names --------------------------------------------------------------------
+_state = {"ctx": None}
+
+
+def fd_init(order, nxe, nze, nxb, nzb, nt, ns, fac, dx, dz, dt):
+    """fd_init (fd-code.cu:200): creates the process-global propagation state like the reference."""
+    if _state["ctx"] is not None:
+        _state["ctx"].close()
+    _state["ctx"] = FDWave(order, nxe, nze, nxb, nzb, nt, fac, dx, dz, dt, compat=True)
+    return _state["ctx"]
+
+
+def fd_forward(order, p, pp, v2, nz, nx, nt, is_, sz, sx, srce, propag=0):
+    """fd_forward (fd-code.cu:247): note the reference's nz-before-nx order; p/pp are updated in place."""
+    ctx = _state["ctx"]
+    if ctx is None:
+        raise _lib.FdwError(_lib.FDW_ESTATE, "fd_init has not been called")
+    P, PP = ctx.forward(v2, int(sx[is_]), sz, srce, p, pp, nt)
+    p[...] = P
+    pp[...] = PP
+
+
+def fd_back(order, p, pp, pr, ppr, v2, nz, nx, nt, is_, sz, gz, snaps, imloc, d_obs):
+    """fd_back (fd-code.cu:290): d_obs[is] is the [nx][nt] gather; imloc is accumulated in place."""
+    ctx = _state["ctx"]
+    if ctx is None:
+        raise _lib.FdwError(_lib.FDW_ESTATE, "fd_init has not been called")
+    imloc[...] = ctx.back(v2, snaps[0], snaps[1], np.asarray(d_obs[is_]).reshape(ctx.nx, ctx.nt), gz, imloc, nt)

@@ -1,0 +1,654 @@
+// fdw_api.cpp -- the C ABI of libfdwave.so (include/fdwave.h) on top of the gfx950 kernels.
+//
+// Replaces the reference's L2 seam: fd_init / fd_init_cuda / write_buffers / fd_forward / fd_back of
+// cuda_reference_RTM/src/fd-code.cu (R) and fd_init / the single launch of
+// cuda_reference_stencil_computation/fd-source-code.cu (S).  There is no CPU compute path in this
+// library: if HIP cannot be initialised on a gfx950 device fdw_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "fdw_kernels.h"
+#include "fdwave.h"
+
+using namespace fdw;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(call)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) return fail(FDW_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                            \
+    } while (0)
+
+extern "C" const char* fdw_last_error(void) { return g_err; }
+extern "C" int fdw_version(void) { return FDW_VERSION; }
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct fdw_ctx {
+    fdw_params prm{};
+    fdw_slab slab{};
+    int device = 0;
+    int h = 0, pitch = 0, nxl = 0;
+    int nx = 0, nz = 0;            // interior size of the GLOBAL grid
+    int xlim = 0, zlim = 0, ztap = 0;  // global launch extents (R:185-195)
+    // local-row translations
+    int lap_x0 = 0, lap_x1 = 0, lap_z0 = 0, lap_z1 = 0;     // RTM modes
+    int slap_x0 = 0, slap_x1 = 0, slap_z0 = 0, slap_z1 = 0; // stencil program (full interior)
+    int upd_x1 = 0, upd_z1 = 0, tz_x1 = 0;
+    float dt2 = 0.f;
+    float cx[FDW_MAX_ORDER + 1]{}, cz[FDW_MAX_ORDER + 1]{};    // RTM weights (C libm variant unless coef_cxx)
+    std::vector<float> taper_x, taper_z, txfac;
+    // device tables
+    float *d_taperz = nullptr, *d_txfac = nullptr, *d_gcx = nullptr, *d_gcz = nullptr;
+    hipStream_t stream = nullptr;
+    // lazily allocated work buffers of the host-array API
+    float* fld[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *d_v2 = nullptr, *d_img = nullptr, *d_srce = nullptr, *d_dobs = nullptr;
+    size_t srce_cap = 0, dobs_cap = 0;
+    // tuning
+    int xchunk = 0, wz = 0, use_generic = 0;
+};
+
+static size_t field_elems(const fdw_ctx* c) { return (size_t)c->nxl * (size_t)c->pitch; }
+
+extern "C" int fdw_pitch(const fdw_ctx* c) { return c ? c->pitch : 0; }
+extern "C" size_t fdw_field_bytes(const fdw_ctx* c) { return c ? field_elems(c) * sizeof(float) : 0; }
+
+static int is_full_grid(const fdw_ctx* c) { return c->slab.x_off == 0 && c->nxl == c->prm.nxe; }
+
+static hipStream_t pick_stream(fdw_ctx* c, void* s) { return s ? (hipStream_t)s : c->stream; }
+
+static int alloc_zero(float** p, size_t elems)
+{
+    if (*p) return FDW_OK;
+    hipError_t e = hipMalloc((void**)p, elems * sizeof(float));
+    if (e != hipSuccess) return fail(FDW_ENOMEM, "hipMalloc(%zu bytes) failed: %s", elems * sizeof(float), hipGetErrorString(e));
+    HIP_TRY(hipMemset(*p, 0, elems * sizeof(float)));
+    HIP_TRY(hipDeviceSynchronize());   // the context stream is non-blocking: do not let it overtake the memset
+    return FDW_OK;
+}
+
+static int ensure_work_buffers(fdw_ctx* c, int nfields, bool need_img)
+{
+    for (int i = 0; i < nfields; i++) {
+        int rc = alloc_zero(&c->fld[i], field_elems(c));
+        if (rc) return rc;
+    }
+    int rc = alloc_zero(&c->d_v2, field_elems(c));
+    if (rc) return rc;
+    if (need_img) {
+        rc = alloc_zero(&c->d_img, field_elems(c));
+        if (rc) return rc;
+    }
+    return FDW_OK;
+}
+
+static int ensure_cap(float** p, size_t* cap, size_t elems)
+{
+    if (*cap >= elems && *p) return FDW_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc((void**)p, std::max<size_t>(elems, 1) * sizeof(float));
+    if (e != hipSuccess) return fail(FDW_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    *cap = elems;
+    return FDW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// create / destroy
+// ------------------------------------------------------------------------------------------------
+static int validate(const fdw_params* p, const fdw_slab* s)
+{
+    if (!p) return fail(FDW_EINVAL, "params is NULL");
+    if (p->order < 2 || p->order > FDW_MAX_ORDER || (p->order & 1))
+        return fail(FDW_EINVAL, "order=%d must be even and in [2,%d]", p->order, FDW_MAX_ORDER);
+    if (p->nxe <= p->order || p->nze <= p->order)
+        return fail(FDW_EINVAL, "grid %dx%d too small for order %d", p->nxe, p->nze, p->order);
+    if (p->nxb < 0 || p->nzb < 0 || 2 * p->nxb >= p->nxe || 2 * p->nzb >= p->nze)
+        return fail(FDW_EINVAL, "borders nxb=%d nzb=%d do not leave an interior in %dx%d", p->nxb, p->nzb, p->nxe, p->nze);
+    if ((p->nxb > 0 || p->nzb > 0) && !(p->fac > 0.0f && p->fac <= 1.0f))
+        return fail(FDW_EINVAL, "fac=%g must be in (0,1]", (double)p->fac);
+    if (!(p->dx > 0.0f) || !(p->dz > 0.0f)) return fail(FDW_EINVAL, "dx, dz must be positive");
+    if (p->nt < 0) return fail(FDW_EINVAL, "nt=%d is negative", p->nt);
+    if (s->nxl <= p->order || s->x_off < 0 || s->x_off + s->nxl > p->nxe)
+        return fail(FDW_EINVAL, "slab [%d,%d) does not fit the grid (nxe=%d) or is thinner than the stencil",
+                    s->x_off, s->x_off + s->nxl, p->nxe);
+    return FDW_OK;
+}
+
+extern "C" int fdw_create_slab(const fdw_params* prm, const fdw_slab* slab, int device, fdw_ctx** out)
+{
+    if (!out) return fail(FDW_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!slab) return fail(FDW_EINVAL, "slab is NULL");
+    int rc = validate(prm, slab);
+    if (rc) return rc;
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(FDW_ENODEVICE, "no HIP device available (%s); libfdwave has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= ndev) return fail(FDW_ENODEVICE, "device %d out of range (have %d)", device, ndev);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+        return fail(FDW_ENODEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(FDW_ENODEVICE, "device %d is %s; libfdwave is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail(FDW_ENODEVICE, "hipSetDevice: %s", hipGetErrorString(e));
+
+    fdw_ctx* c = new (std::nothrow) fdw_ctx();
+    if (!c) return fail(FDW_ENOMEM, "out of host memory");
+    c->prm = *prm;
+    c->slab = *slab;
+    c->device = device;
+    c->h = prm->order / 2;
+    c->nxl = slab->nxl;
+    c->nx = prm->nxe - 2 * prm->nxb;
+    c->nz = prm->nze - 2 * prm->nzb;
+    c->pitch = ((prm->nze + 63) / 64) * 64;  // 256-B aligned rows: every lane's float4 is aligned
+
+    // launch extents, R:185-195 (the int assignment truncates before ceil)
+    if (prm->compat) {
+        c->xlim = 8 * (prm->nxe / 8);
+        c->zlim = 8 * (prm->nze / 8);
+        c->ztap = 8 * (prm->nzb / 8);
+    } else {
+        c->xlim = prm->nxe;
+        c->zlim = prm->nze;
+        c->ztap = prm->nzb;
+    }
+    const int h = c->h, xo = slab->x_off;
+    // kernel_lap covers i = h + t, t < xlim threads, and i < nxe - h (R:56-64)
+    const int glx0 = h, glx1 = std::min(prm->nxe - h, h + c->xlim);
+    c->lap_x0 = std::max(h, glx0 - xo);
+    c->lap_x1 = std::min(c->nxl - h, glx1 - xo);
+    c->lap_z0 = h;
+    c->lap_z1 = std::min(prm->nze - h, h + c->zlim);
+    // the stencil program rounds its grid up to 32 (S:231-238): whole interior
+    c->slap_x0 = std::max(h, h - xo);
+    c->slap_x1 = std::min(c->nxl - h, prm->nxe - h - xo);
+    c->slap_z0 = h;
+    c->slap_z1 = prm->nze - h;
+    c->upd_x1 = std::max(0, std::min(c->nxl, c->xlim - xo));
+    c->upd_z1 = c->zlim;
+    c->tz_x1 = c->upd_x1;
+
+    // derived constants, R:203-217 (double quotient narrowed to float; float*float scaling)
+    const float dx2inv = (1. / prm->dx) * (1. / prm->dx);
+    const float dz2inv = (1. / prm->dz) * (1. / prm->dz);
+    c->dt2 = prm->dt * prm->dt;
+    float w[FDW_MAX_ORDER + 1];
+    fdw_calc_coefs(prm->order, prm->coef_cxx, w);
+    for (int io = 0; io <= prm->order; io++) {
+        c->cz[io] = dz2inv * w[io];
+        c->cx[io] = dx2inv * w[io];
+    }
+    c->taper_x.assign(std::max(prm->nxb, 1), 1.0f);
+    c->taper_z.assign(std::max(prm->nzb, 1), 1.0f);
+    if (prm->nxb > 0) fdw_taper_tables(prm->nxb, 0, prm->fac, c->taper_x.data(), nullptr);
+    if (prm->nzb > 0) fdw_taper_tables(0, prm->nzb, prm->fac, nullptr, c->taper_z.data());
+    // per-row x factor: thread i < nxb (and < xlim) scales columns i and nxe-1-i by taperx[i] (R:108-115)
+    c->txfac.assign(c->nxl, 1.0f);
+    for (int l = 0; l < c->nxl; l++) {
+        const int g = xo + l, gm = prm->nxe - 1 - g;
+        if (g < prm->nxb && g < c->xlim) c->txfac[l] = c->taper_x[g];
+        else if (gm < prm->nxb && gm < c->xlim) c->txfac[l] = c->taper_x[gm];
+    }
+
+#define CREATE_TRY(call)                                                                                  \
+    do {                                                                                                  \
+        hipError_t e2_ = (call);                                                                          \
+        if (e2_ != hipSuccess) {                                                                          \
+            fail(FDW_EHIP, "%s failed: %s", #call, hipGetErrorString(e2_));                               \
+            fdw_destroy(c);                                                                               \
+            return FDW_EHIP;                                                                              \
+        }                                                                                                 \
+    } while (0)
+    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t ntz = std::max(c->ztap, 1);
+    CREATE_TRY(hipMalloc((void**)&c->d_taperz, ntz * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&c->d_txfac, c->nxl * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&c->d_gcx, (FDW_MAX_ORDER + 1) * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&c->d_gcz, (FDW_MAX_ORDER + 1) * sizeof(float)));
+    CREATE_TRY(hipMemcpy(c->d_taperz, c->taper_z.data(), std::min<size_t>(ntz, c->taper_z.size()) * sizeof(float), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(c->d_txfac, c->txfac.data(), c->nxl * sizeof(float), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(c->d_gcx, c->cx, (FDW_MAX_ORDER + 1) * sizeof(float), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(c->d_gcz, c->cz, (FDW_MAX_ORDER + 1) * sizeof(float), hipMemcpyHostToDevice));
+#undef CREATE_TRY
+    *out = c;
+    return FDW_OK;
+}
+
+extern "C" int fdw_create(const fdw_params* prm, int device, fdw_ctx** out)
+{
+    if (!prm) return fail(FDW_EINVAL, "params is NULL");
+    fdw_slab s{0, prm->nxe};
+    return fdw_create_slab(prm, &s, device, out);
+}
+
+extern "C" void fdw_destroy(fdw_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    float* bufs[] = {c->d_taperz, c->d_txfac, c->d_gcx, c->d_gcz, c->fld[0], c->fld[1], c->fld[2], c->fld[3],
+                     c->d_v2, c->d_img, c->d_srce, c->d_dobs};
+    for (float* b : bufs)
+        if (b) (void)hipFree(b);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch geometry + one step
+// ------------------------------------------------------------------------------------------------
+static void fill_geometry(const fdw_ctx* c, StepArgs& a, int rows)
+{
+    const int nstrips = (c->pitch + 255) / 256;
+    int wz = c->wz;
+    if (wz != 1 && wz != 2 && wz != 4) wz = nstrips >= 4 ? 4 : (nstrips >= 2 ? 2 : 1);
+    int xchunk = c->xchunk;
+    if (xchunk <= 0) {
+        // aim at ~16 waves per CU on 256 CUs; never less than 8 rows (window refill is 2H rows)
+        const long want = ((long)rows * nstrips + 4095) / 4096;
+        xchunk = (int)std::min<long>(std::max<long>(want, 8), 256);
+    }
+    a.xchunk = xchunk;
+    a.wz = wz;
+    a.nzblk = (nstrips + wz - 1) / wz;
+    const int chunks = (rows + xchunk - 1) / xchunk;
+    const int wpx = 4 / wz;
+    const int nxblk = (chunks + wpx - 1) / wpx;
+    a.nblk = a.nzblk * nxblk;
+    a.nper = (a.nblk + 7) / 8;
+}
+
+static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const float* d_v2, int r0, int r1,
+                     int pp_twice, const float* d_inj, int inj_x_global, int inj_z, const float* d_psrc, float* d_img,
+                     hipStream_t s)
+{
+    const bool lap = (mode == FDW_MODE_LAP);
+    if (!d_p || !d_pp) return fail(FDW_EINVAL, "step: field pointer is NULL");
+    if (!lap && !d_v2) return fail(FDW_EINVAL, "step: v2 is NULL");
+    if (mode == FDW_MODE_RECV && (!d_psrc || !d_img || !d_inj)) return fail(FDW_EINVAL, "step: RECV needs d_inj, d_psrc and d_img");
+    if (mode < FDW_MODE_FWD || mode > FDW_MODE_LAP) return fail(FDW_EINVAL, "step: unknown mode %d", mode);
+    if (r0 < 0 || r1 > c->nxl || r0 > r1) return fail(FDW_EINVAL, "step: rows [%d,%d) outside the slab (%d rows)", r0, r1, c->nxl);
+
+    StepArgs a{};
+    a.p = d_p; a.pp = d_pp; a.v2 = d_v2; a.psrc = d_psrc; a.img = d_img;
+    a.taperz = c->d_taperz; a.txfac = c->d_txfac; a.inj = d_inj; a.gcx = c->d_gcx; a.gcz = c->d_gcz;
+    a.pitch = c->pitch; a.nxl = c->nxl;
+    a.r0 = r0;
+    a.r1 = lap ? r1 : std::min(r1, c->upd_x1);   // rows >= xlim are never time-stepped (R:83-87)
+    a.lap_x0 = lap ? c->slap_x0 : c->lap_x0; a.lap_x1 = lap ? c->slap_x1 : c->lap_x1;
+    a.lap_z0 = lap ? c->slap_z0 : c->lap_z0; a.lap_z1 = lap ? c->slap_z1 : c->lap_z1;
+    a.upd_z1 = c->upd_z1;
+    a.ztap = c->ztap; a.tz_x1 = c->tz_x1;
+    a.pp_twice = pp_twice ? 1 : 0;
+    a.inj_x = -1; a.inj_z = inj_z; a.inj_n = 0;
+    if (mode == FDW_MODE_FWD && d_inj && inj_x_global >= 0) {
+        if (inj_z < 0 || inj_z >= c->prm.nze || inj_x_global >= c->prm.nxe)
+            return fail(FDW_EINVAL, "step: source (%d,%d) outside the grid", inj_x_global, inj_z);
+        a.inj_x = inj_x_global - c->slab.x_off;   // may fall outside this slab: then no row matches
+        if (a.inj_x >= c->upd_x1 && a.inj_x < c->nxl)
+            return fail(FDW_EINVAL, "step: source row %d lies in rows the reference never time-steps (>= %d)", inj_x_global, c->xlim);
+    } else if (mode == FDW_MODE_RECV) {
+        if (inj_z < 0 || inj_z >= c->prm.nze) return fail(FDW_EINVAL, "step: receiver depth %d outside the grid", inj_z);
+        // receivers sit on interior columns nxb..nxb+nx-1 (R:126-129); clip to this slab
+        const int g0 = c->prm.nxb, g1 = c->prm.nxb + std::min(c->nx, c->xlim);
+        const int l0 = std::max(g0 - c->slab.x_off, 0), l1 = std::min(g1 - c->slab.x_off, c->nxl);
+        a.inj_x = l0;
+        a.inj_n = std::max(0, l1 - l0);
+        a.inj = d_inj + (l0 + c->slab.x_off - g0);
+    }
+    a.dt2 = c->dt2;
+    for (int io = 0; io <= 2 * kMaxFastHalfOrder; io++) {
+        a.cx[io] = io <= c->prm.order ? c->cx[io] : 0.0f;
+        a.cz[io] = io <= c->prm.order ? c->cz[io] : 0.0f;
+    }
+    if (a.r1 <= a.r0) return FDW_OK;
+    hipError_t e;
+    if (c->h <= kMaxFastHalfOrder && !c->use_generic) {
+        fill_geometry(c, a, a.r1 - a.r0);
+        e = launch_step_fast(a, c->h, mode, s);
+    } else {
+        e = launch_step_generic(a, c->h, mode, s);
+    }
+    if (e != hipSuccess) return fail(FDW_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return FDW_OK;
+}
+
+extern "C" int fdw_dev_step(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const float* d_v2, int r0, int r1,
+                            int pp_twice, const float* d_inj, int inj_x, int inj_z, const float* d_psrc, float* d_img,
+                            void* stream)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    if (mode == FDW_MODE_LAP) return fail(FDW_EINVAL, "use fdw_dev_laplacian for mode 3");
+    return step_impl(c, mode, d_p, d_pp, d_v2, r0, r1, pp_twice, d_inj, inj_x, inj_z, d_psrc, d_img, pick_stream(c, stream));
+}
+
+extern "C" int fdw_dev_laplacian(fdw_ctx* c, const float* d_p, float* d_lap, void* stream)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    return step_impl(c, FDW_MODE_LAP, d_p, d_lap, nullptr, 0, c->nxl, 0, nullptr, -1, 0, nullptr, nullptr, pick_stream(c, stream));
+}
+
+extern "C" int fdw_dev_steps(fdw_ctx* c, float* d_p, float* d_pp, const float* d_v2, const float* d_srce, int sx, int sz,
+                             int it0, int nsteps, int first_pp_twice, void* stream)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    hipStream_t s = pick_stream(c, stream);
+    for (int k = 0; k < nsteps; k++) {
+        std::swap(d_p, d_pp);  // R:260-262
+        int rc = step_impl(c, FDW_MODE_FWD, d_p, d_pp, d_v2, 0, c->nxl, (k > 0) || first_pp_twice,
+                           d_srce ? d_srce + it0 + k : nullptr, d_srce ? sx : -1, sz, nullptr, nullptr, s);
+        if (rc) return rc;
+    }
+    return FDW_OK;
+}
+
+extern "C" int fdw_dev_taper_finalize(fdw_ctx* c, float* d_f, void* stream)
+{
+    if (!c || !d_f) return fail(FDW_EINVAL, "ctx or field is NULL");
+    hipError_t e = launch_taper_finalize(d_f, c->d_taperz, c->d_txfac, c->pitch, c->nxl, c->ztap, c->tz_x1, pick_stream(c, stream));
+    if (e != hipSuccess) return fail(FDW_EHIP, "taper finalize launch failed: %s", hipGetErrorString(e));
+    return FDW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host <-> device transfers
+// ------------------------------------------------------------------------------------------------
+static int upload_rows(fdw_ctx* c, float* d_dst, const float* h_src, hipStream_t s)
+{
+    HIP_TRY(hipMemcpy2DAsync(d_dst, (size_t)c->pitch * sizeof(float), h_src, (size_t)c->prm.nze * sizeof(float),
+                             (size_t)c->prm.nze * sizeof(float), c->nxl, hipMemcpyHostToDevice, s));
+    return FDW_OK;
+}
+static int download_rows(fdw_ctx* c, float* h_dst, const float* d_src, hipStream_t s)
+{
+    HIP_TRY(hipMemcpy2DAsync(h_dst, (size_t)c->prm.nze * sizeof(float), d_src, (size_t)c->pitch * sizeof(float),
+                             (size_t)c->prm.nze * sizeof(float), c->nxl, hipMemcpyDeviceToHost, s));
+    return FDW_OK;
+}
+
+extern "C" int fdw_upload_field(fdw_ctx* c, float* d_dst, const float* h_src)
+{
+    if (!c || !d_dst || !h_src) return fail(FDW_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = upload_rows(c, d_dst, h_src, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FDW_OK;
+}
+extern "C" int fdw_download_field(fdw_ctx* c, float* h_dst, const float* d_src)
+{
+    if (!c || !h_dst || !d_src) return fail(FDW_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = download_rows(c, h_dst, d_src, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FDW_OK;
+}
+
+// The reference damps rows >= xlim of the top strip with taperx only, every step, in place; the lazy
+// scheme cannot reproduce that for rows that are never rewritten.  Those cells are zero at every call
+// site of the reference (R:496-497, R:511-514 and snapshots of such runs), so we require it.
+static int check_static_taper_rows(const fdw_ctx* c, const float* f, const char* name)
+{
+    if (c->xlim >= c->prm.nxe || c->ztap <= 0) return FDW_OK;
+    for (int i = c->xlim; i < c->prm.nxe; i++)
+        for (int j = 0; j < c->ztap; j++)
+            if (f[(size_t)i * c->prm.nze + j] != 0.0f)
+                return fail(FDW_EINVAL, "%s[%d][%d] != 0: in compat mode rows >= %d of the damped strip must be zero "
+                                        "(they are never time-stepped by the reference, R:185-195)", name, i, j, c->xlim);
+    return FDW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-array entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int fdw_laplacian(fdw_ctx* c, const float* p, float* lap)
+{
+    if (!c || !p || !lap) return fail(FDW_EINVAL, "NULL argument");
+    if (!is_full_grid(c)) return fail(FDW_EINVAL, "fdw_laplacian needs a full-grid context");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_work_buffers(c, 2, false);
+    if (rc) return rc;
+    if ((rc = upload_rows(c, c->fld[0], p, c->stream))) return rc;
+    if ((rc = step_impl(c, FDW_MODE_LAP, c->fld[0], c->fld[1], nullptr, 0, c->nxl, 0, nullptr, -1, 0, nullptr, nullptr, c->stream))) return rc;
+    if ((rc = download_rows(c, lap, c->fld[1], c->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FDW_OK;
+}
+
+static int upload_source(fdw_ctx* c, const float* srce, int n)
+{
+    int rc = ensure_cap(&c->d_srce, &c->srce_cap, (size_t)std::max(n, 1));
+    if (rc) return rc;
+    if (n > 0) HIP_TRY(hipMemcpyAsync(c->d_srce, srce, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    return FDW_OK;
+}
+
+// fd_forward's loop body R:259-267 for nsteps iterations on device buffers; returns the final roles.
+static int forward_loop(fdw_ctx* c, float** d_p, float** d_pp, int sx, int sz, int nsteps)
+{
+    for (int it = 0; it < nsteps; it++) {
+        std::swap(*d_p, *d_pp);
+        int rc = step_impl(c, FDW_MODE_FWD, *d_p, *d_pp, c->d_v2, 0, c->nxl, it > 0, c->d_srce + it, sx, sz, nullptr, nullptr, c->stream);
+        if (rc) return rc;
+    }
+    if (nsteps > 0) return fdw_dev_taper_finalize(c, *d_p, c->stream);   // the T() d_p still owes (R:285 downloads the damped d_p)
+    return FDW_OK;
+}
+
+extern "C" int fdw_forward(fdw_ctx* c, float* p, float* pp, const float* v2, int sx, int sz, const float* srce, int nsteps)
+{
+    if (!c || !p || !pp || !v2 || (!srce && nsteps > 0)) return fail(FDW_EINVAL, "NULL argument");
+    if (!is_full_grid(c)) return fail(FDW_EINVAL, "fdw_forward needs a full-grid context");
+    if (nsteps < 0) return fail(FDW_EINVAL, "nsteps=%d", nsteps);
+    int rc;
+    if ((rc = check_static_taper_rows(c, p, "p")) || (rc = check_static_taper_rows(c, pp, "pp"))) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = ensure_work_buffers(c, 2, false))) return rc;
+    float *d_p = c->fld[0], *d_pp = c->fld[1];
+    if ((rc = upload_rows(c, d_p, p, c->stream)) || (rc = upload_rows(c, d_pp, pp, c->stream)) ||
+        (rc = upload_rows(c, c->d_v2, v2, c->stream)) || (rc = upload_source(c, srce, nsteps)))
+        return rc;
+    if ((rc = forward_loop(c, &d_p, &d_pp, sx, sz, nsteps))) return rc;
+    if ((rc = download_rows(c, p, d_p, c->stream)) || (rc = download_rows(c, pp, d_pp, c->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FDW_OK;
+}
+
+// d_obs [nx][nt] (R:426-435) -> device [nt][nx] so that one step's samples are contiguous
+static int upload_gather(fdw_ctx* c, const float* d_obs)
+{
+    const size_t nx = c->nx, nt = c->prm.nt;
+    int rc = ensure_cap(&c->d_dobs, &c->dobs_cap, nx * nt);
+    if (rc) return rc;
+    std::vector<float> t(nx * nt);
+    for (size_t i = 0; i < nx; i++)
+        for (size_t k = 0; k < nt; k++) t[k * nx + i] = d_obs[i * nt + k];
+    HIP_TRY(hipMemcpy(c->d_dobs, t.data(), nx * nt * sizeof(float), hipMemcpyHostToDevice));
+    return FDW_OK;
+}
+
+static int image_to_device(fdw_ctx* c, const float* imloc)
+{
+    HIP_TRY(hipMemsetAsync(c->d_img, 0, field_elems(c) * sizeof(float), c->stream));
+    float* dst = c->d_img + (size_t)c->prm.nxb * c->pitch + c->prm.nzb;
+    HIP_TRY(hipMemcpy2DAsync(dst, (size_t)c->pitch * sizeof(float), imloc, (size_t)c->nz * sizeof(float),
+                             (size_t)c->nz * sizeof(float), c->nx, hipMemcpyHostToDevice, c->stream));
+    return FDW_OK;
+}
+static int image_to_host(fdw_ctx* c, float* imloc)
+{
+    const float* src = c->d_img + (size_t)c->prm.nxb * c->pitch + c->prm.nzb;
+    HIP_TRY(hipMemcpy2DAsync(imloc, (size_t)c->nz * sizeof(float), src, (size_t)c->pitch * sizeof(float),
+                             (size_t)c->nz * sizeof(float), c->nx, hipMemcpyDeviceToHost, c->stream));
+    return FDW_OK;
+}
+
+// fd_back's loop R:302-339.  The two snapshots are either host arrays (uploaded into d_pp at it=0,1
+// exactly like R:304-314) or already on the device (dsnap0/dsnap1, used in place).
+static int back_loop(fdw_ctx* c, const float* hsnap0, const float* hsnap1, float* dsnap0, float* dsnap1, int gz, int nsteps)
+{
+    float *d_p, *d_pp, *d_pr = c->fld[2], *d_ppr = c->fld[3];
+    const bool resident = (dsnap0 != nullptr);
+    if (resident) {
+        d_p = nullptr; d_pp = nullptr;
+    } else {
+        d_p = c->fld[0]; d_pp = c->fld[1];
+        HIP_TRY(hipMemsetAsync(d_p, 0, field_elems(c) * sizeof(float), c->stream));
+        HIP_TRY(hipMemsetAsync(d_pp, 0, field_elems(c) * sizeof(float), c->stream));
+    }
+    HIP_TRY(hipMemsetAsync(d_pr, 0, field_elems(c) * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(d_ppr, 0, field_elems(c) * sizeof(float), c->stream));
+    const int nt = c->prm.nt;
+    for (int it = 0; it < nsteps; it++) {
+        int rc;
+        if (resident) {
+            // it=0: source field = u^nt (dsnap1); it=1: u^{nt-1} (dsnap0); afterwards step backwards in time
+            if (it == 0) { d_p = dsnap1; d_pp = dsnap0; }
+            else if (it == 1) { d_p = dsnap0; d_pp = dsnap1; }
+            else {
+                if ((rc = step_impl(c, FDW_MODE_PLAIN, d_p, d_pp, c->d_v2, 0, c->nxl, 0, nullptr, -1, 0, nullptr, nullptr, c->stream))) return rc;
+                std::swap(d_p, d_pp);
+            }
+        } else {
+            if (it < 2) {
+                if ((rc = upload_rows(c, d_pp, it == 0 ? hsnap1 : hsnap0, c->stream))) return rc;
+            } else {
+                if ((rc = step_impl(c, FDW_MODE_PLAIN, d_p, d_pp, c->d_v2, 0, c->nxl, 0, nullptr, -1, 0, nullptr, nullptr, c->stream))) return rc;
+            }
+            std::swap(d_p, d_pp);  // R:321-323
+        }
+        const float* samples = c->d_dobs + (size_t)(nt - 1 - it) * c->nx;
+        if ((rc = step_impl(c, FDW_MODE_RECV, d_pr, d_ppr, c->d_v2, 0, c->nxl, it > 0, samples, 0, gz, d_p, c->d_img, c->stream))) return rc;
+        std::swap(d_pr, d_ppr);  // R:331-333
+    }
+    return FDW_OK;
+}
+
+extern "C" int fdw_back(fdw_ctx* c, const float* v2, const float* snap0, const float* snap1, const float* d_obs, int gz,
+                        float* imloc, int nsteps)
+{
+    if (!c || !v2 || !snap0 || !snap1 || !d_obs || !imloc) return fail(FDW_EINVAL, "NULL argument");
+    if (!is_full_grid(c)) return fail(FDW_EINVAL, "fdw_back needs a full-grid context");
+    if (nsteps < 0 || nsteps > c->prm.nt) return fail(FDW_EINVAL, "nsteps=%d outside [0,nt=%d]", nsteps, c->prm.nt);
+    if (c->nx <= 0 || c->nz <= 0) return fail(FDW_EINVAL, "no interior to image");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_work_buffers(c, 4, true))) return rc;
+    if ((rc = upload_rows(c, c->d_v2, v2, c->stream)) || (rc = upload_gather(c, d_obs)) || (rc = image_to_device(c, imloc))) return rc;
+    if ((rc = back_loop(c, snap0, snap1, nullptr, nullptr, gz, nsteps))) return rc;
+    if ((rc = image_to_host(c, imloc))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FDW_OK;
+}
+
+extern "C" int fdw_shot(fdw_ctx* c, const float* v2, int sx, int sz, int gz, const float* srce, const float* d_obs,
+                        float* imloc, float* P, float* PP)
+{
+    if (!c || !v2 || !srce || !d_obs || !imloc) return fail(FDW_EINVAL, "NULL argument");
+    if (!is_full_grid(c)) return fail(FDW_EINVAL, "fdw_shot needs a full-grid context");
+    if (c->nx <= 0 || c->nz <= 0) return fail(FDW_EINVAL, "no interior to image");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    const int nt = c->prm.nt;
+    if ((rc = ensure_work_buffers(c, 4, true))) return rc;
+    float *d_p = c->fld[0], *d_pp = c->fld[1];
+    HIP_TRY(hipMemsetAsync(d_p, 0, field_elems(c) * sizeof(float), c->stream));    // R:496-497
+    HIP_TRY(hipMemsetAsync(d_pp, 0, field_elems(c) * sizeof(float), c->stream));
+    if ((rc = upload_rows(c, c->d_v2, v2, c->stream)) || (rc = upload_source(c, srce, nt)) || (rc = upload_gather(c, d_obs)) ||
+        (rc = image_to_device(c, imloc)))
+        return rc;
+    if ((rc = forward_loop(c, &d_p, &d_pp, sx, sz, nt))) return rc;
+    if (P && (rc = download_rows(c, P, d_p, c->stream))) return rc;
+    if (PP && (rc = download_rows(c, PP, d_pp, c->stream))) return rc;
+    if ((rc = back_loop(c, nullptr, nullptr, d_p, d_pp, gz, nt))) return rc;
+    if ((rc = image_to_host(c, imloc))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FDW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tuning / introspection
+// ------------------------------------------------------------------------------------------------
+extern "C" int fdw_set_tuning(fdw_ctx* c, int xchunk, int wz, int use_generic)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    if (xchunk < 0 || (wz != 0 && wz != 1 && wz != 2 && wz != 4)) return fail(FDW_EINVAL, "bad tuning xchunk=%d wz=%d", xchunk, wz);
+    c->xchunk = xchunk;
+    c->wz = wz;
+    c->use_generic = use_generic ? 1 : 0;
+    return FDW_OK;
+}
+
+extern "C" int fdw_get_tables(const fdw_ctx* c, float* coefs_x, float* coefs_z, float* taper_x, float* taper_z)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    if (coefs_x) memcpy(coefs_x, c->cx, (c->prm.order + 1) * sizeof(float));
+    if (coefs_z) memcpy(coefs_z, c->cz, (c->prm.order + 1) * sizeof(float));
+    if (taper_x && c->prm.nxb > 0) memcpy(taper_x, c->taper_x.data(), c->prm.nxb * sizeof(float));
+    if (taper_z && c->prm.nzb > 0) memcpy(taper_z, c->taper_z.data(), c->prm.nzb * sizeof(float));
+    return FDW_OK;
+}
+
+extern "C" int fdw_get_extents(const fdw_ctx* c, int* xlim, int* zlim, int* ztap)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    if (xlim) *xlim = c->xlim;
+    if (zlim) *zlim = c->zlim;
+    if (ztap) *ztap = c->ztap;
+    return FDW_OK;
+}
+
+extern "C" int fdw_selftest(fdw_ctx* c)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    float h_src[64], h_old[64], h_out[128];
+    for (int i = 0; i < 64; i++) { h_src[i] = 100.0f + i; h_old[i] = -1.0f - i; }
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 256 * sizeof(float)));
+    hipError_t e = hipMemcpy(d, h_src, sizeof h_src, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + 64, h_old, sizeof h_old, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_dpp_selftest(d, d + 64, d + 128, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(h_out, d + 128, sizeof h_out, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(FDW_EHIP, "selftest: %s", hipGetErrorString(e));
+    for (int i = 0; i < 64; i++) {
+        const float want_r = i == 0 ? h_old[0] : h_src[i - 1];
+        const float want_l = i == 63 ? h_old[63] : h_src[i + 1];
+        if (h_out[i] != want_r || h_out[64 + i] != want_l)
+            return fail(FDW_EHIP, "selftest: DPP wave shift mismatch at lane %d (shr %g want %g, shl %g want %g)", i,
+                        (double)h_out[i], (double)want_r, (double)h_out[64 + i], (double)want_l);
+    }
+    return FDW_OK;
+}

@@ -1,0 +1,48 @@
+// fdw_kernels.h -- internal interface between the C-ABI layer (fdw_api.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fdw {
+
+enum {
+    FDW_MODE_FWD = 0,    // taper + Laplacian + leap-frog + point source   (fd_forward body, R:264-267)
+    FDW_MODE_PLAIN = 1,  // Laplacian + leap-frog only                     (fd_back source field, R:317-318)
+    FDW_MODE_RECV = 2,   // taper + Laplacian + leap-frog + receivers + imaging (R:325-329)
+    FDW_MODE_LAP = 3     // Laplacian only, written to `pp`                (stencil_code, S:325)
+};
+
+constexpr int kMaxFastHalfOrder = 4;   // register-window kernel is instantiated for order 2,4,6,8
+
+// Everything one launch needs, passed by value (lives in SGPRs / the scalar cache).
+// All row indices are LOCAL rows of this device's slab; the host translates global extents.
+struct StepArgs {
+    const float* p;        // [nxl][pitch] newest field (read only in this launch)
+    float* pp;             // [nxl][pitch] older field, overwritten with the new one (or Laplacian out)
+    const float* v2;       // [nxl][pitch] squared velocity
+    const float* psrc;     // IMG: source wavefield to correlate with
+    float* img;            // IMG: image accumulator on the extended grid
+    const float* taperz;   // [ztap] z damping factors
+    const float* txfac;    // [nxl] per-row x damping factor (1.0f where none applies)
+    const float* inj;      // INJ=1: one source sample; INJ=2: inj_n receiver samples of this step
+    const float* gcx;      // generic kernel: device copies of the scaled coefficients
+    const float* gcz;
+    int pitch, nxl;
+    int r0, r1;            // rows updated by this launch (already clipped to rows < upd_x1)
+    int lap_x0, lap_x1;    // rows / columns where the Laplacian is evaluated (0 elsewhere)
+    int lap_z0, lap_z1;
+    int upd_z1;            // columns >= upd_z1 keep their old value (reference launch extent)
+    int ztap, tz_x1;       // damped strip: z < ztap; rows < tz_x1 get the z factor
+    int pp_twice;          // pp owes the previous step's T() (all steps but the first after an upload)
+    int inj_x, inj_z, inj_n;
+    int xchunk, wz, nzblk, nblk, nper;  // launch geometry (fast kernel)
+    float dt2;
+    float cx[2 * kMaxFastHalfOrder + 1], cz[2 * kMaxFastHalfOrder + 1];
+};
+
+hipError_t launch_step_fast(const StepArgs& a, int half_order, int mode, hipStream_t s);
+hipError_t launch_step_generic(const StepArgs& a, int half_order, int mode, hipStream_t s);
+hipError_t launch_taper_finalize(float* f, const float* taperz, const float* txfac, int pitch, int nxl, int ztap,
+                                 int tz_x1, hipStream_t s);
+hipError_t launch_dpp_selftest(const float* src, const float* old, float* out, hipStream_t s);
+
+}  // namespace fdw

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures from the reference tree (run in the authoring container
+only: `python tests/golden/make_golden.py`).  Fixtures are DATA: binary fields the reference ships,
+and tables produced by the reference's own host library compiled unmodified (oracle/_ref, built by
+oracle/Makefile from cuda_reference_RTM/lib/src/functions.c).  No reference source text is copied.
+
+  stencil_input_415x295.f32   cuda_reference_stencil_computation/input.bin  (real-hardware output: P of
+                              fd_forward, shot 5 of models/new_mod, after 1700 steps; also the input of
+                              the Laplacian known-answer test)
+  stencil_lap_415x295.f32     dpct_migrated_stencil_computation/output_teste.bin (8th-order Laplacian of it)
+  new_mod_vel_ext_shot5.f32   slice [5] of cuda_reference_RTM/models/new_mod/vel_ext_rnd.6 (415x295)
+  new_mod_vel_koslov.f32      cuda_reference_RTM/models/new_mod/vel-koslov.1 (315x195)
+  host_tables.npz             calc_coefs / ricker_wavelet / extendvel_linear outputs of oracle/_ref
+  decks/*.dat                 the reference's input.dat decks (parser fixtures)
+"""
+import ctypes as C
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = os.environ.get("FDW_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+
+def main():
+    cp = lambda src, dst: shutil.copyfile(os.path.join(REF, src), os.path.join(HERE, dst))
+    cp("cuda_reference_stencil_computation/input.bin", "stencil_input_415x295.f32")
+    cp("dpct_migrated_stencil_computation/output_teste.bin", "stencil_lap_415x295.f32")
+    cp("cuda_reference_RTM/models/new_mod/vel-koslov.1", "new_mod_vel_koslov.f32")
+    vel = np.fromfile(os.path.join(REF, "cuda_reference_RTM/models/new_mod/vel_ext_rnd.6"), np.float32).reshape(6, 415, 295)
+    vel[5].tofile(os.path.join(HERE, "new_mod_vel_ext_shot5.f32"))
+    for name, src in [("stencil.dat", "cuda_reference_stencil_computation/input.dat"),
+                      ("new_mod.dat", "cuda_reference_RTM/models/new_mod/input.dat"),
+                      ("marmousi.dat", "cuda_reference_RTM/models/marmousi/input.dat"),
+                      ("1lay_mod.dat", "cuda_reference_RTM/models/1lay_mod/input.dat"),
+                      ("3lay_mod.dat", "cuda_reference_RTM/models/3lay_mod/input.dat")]:
+        cp(src, os.path.join("decks", name))
+
+    L = O.ref_lib()
+    assert L is not None, "build oracle/_ref first (make -C oracle)"
+    out = {}
+    for order in (2, 4, 6, 8, 10, 12, 14, 16, 20, 32):
+        r = L.calc_coefs(order)
+        out[f"coefs_{order}"] = np.array([r[i] for i in range(order + 1)], np.float32)
+    for nt, dt, fp in ((1700, 0.001, 20.0), (64, 0.001, 20.0), (401, 0.001, 40.0), (3004, 0.001, 6.5)):
+        s = np.zeros(nt, np.float32)
+        L.ricker_wavelet(nt, dt, fp, s)
+        out[f"ricker_{nt}_{fp}"] = s
+    libc = C.CDLL(None)
+
+    def ref_extend(vp, nx, nz, nxb, nzb, seed):
+        a = np.zeros((nx + 2 * nxb, nz + 2 * nzb), np.float32)
+        a[nxb:nxb + nx, nzb:nzb + nz] = vp
+        rows = (C.POINTER(C.c_float) * a.shape[0])(*[C.cast(a[i].ctypes.data, C.POINTER(C.c_float)) for i in range(a.shape[0])])
+        libc.srand(seed)
+        L.extendvel_linear(nx, nz, nxb, nzb, rows)
+        return a
+
+    rng = np.random.default_rng(7)
+    small = (1500 + 2500 * rng.random((24, 20))).astype(np.float32)
+    out["extvel_small_in"] = small
+    out["extvel_small_seed1"] = ref_extend(small, 24, 20, 6, 5, 1)
+    out["extvel_small_seed42"] = ref_extend(small, 24, 20, 6, 5, 42)
+    vk = np.fromfile(os.path.join(HERE, "new_mod_vel_koslov.f32"), np.float32).reshape(315, 195)
+    # the reference never seeds rand(): the first extendvel_linear call of a process sees seed 1
+    out["extvel_new_mod_seed1"] = ref_extend(vk, 315, 195, 50, 50, 1)
+    np.savez_compressed(os.path.join(HERE, "host_tables.npz"), **out)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
