@@ -138,14 +138,16 @@ int fdw_download_field(fdw_ctx *ctx, float *h_dst, const float *d_src);
 
 /* ---- tuning / introspection --------------------------------------------------------------------
  * fdw_set_tuning  xchunk = rows marched per wave (0 = auto), wz = waves of a block laid along z
- *                 (1,2,4; 0 = auto), use_generic = force the generic-order kernel (tests).
+ *                 (1,2,4; 0 = auto), use_generic = force the generic-order kernel (tests),
+ *                 prefetch = software prefetch distance in rows (0 = default; 1..3, order 8 only),
+ *                 force_edge = run every wave through the general masked body (tests).
  * fdw_get_tables  copies of the derived host tables (any pointer may be NULL):
  *                 coefs_x/z[order+1] (R:214-217), taper_x[nxb], taper_z[nzb] (R:159-166).
  * fdw_get_extents xlim/zlim = rows/columns the time update covers, ztap = damped columns (R:185-195).
  * fdw_selftest    runs the DPP wave-shift self test on the device; 0 if the hardware behaves as the
  *                 step kernel assumes.
  */
-int fdw_set_tuning(fdw_ctx *ctx, int xchunk, int wz, int use_generic);
+int fdw_set_tuning(fdw_ctx *ctx, int xchunk, int wz, int use_generic, int prefetch, int force_edge);
 int fdw_get_tables(const fdw_ctx *ctx, float *coefs_x, float *coefs_z, float *taper_x, float *taper_z);
 int fdw_get_extents(const fdw_ctx *ctx, int *xlim, int *zlim, int *ztap);
 int fdw_selftest(fdw_ctx *ctx);

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfdwave.so")
+LIB_PATH = os.environ.get("FDW_LIB") or os.path.join(_HERE, "libfdwave.so")   # FDW_LIB: experiment builds only
 
 f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 vp = C.c_void_p
@@ -50,7 +50,7 @@ SIGNATURES = [
     ("fdw_dev_laplacian", C.c_int, [vp, vp, vp, vp]),
     ("fdw_upload_field", C.c_int, [vp, vp, f32p]),
     ("fdw_download_field", C.c_int, [vp, f32p, vp]),
-    ("fdw_set_tuning", C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+    ("fdw_set_tuning", C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("fdw_get_tables", C.c_int, [vp, vp, vp, vp, vp]),
     ("fdw_get_extents", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("fdw_selftest", C.c_int, [vp]),

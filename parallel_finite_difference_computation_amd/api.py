@@ -95,8 +95,8 @@ class FDWave:
         check(lib().fdw_get_extents(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
-    def set_tuning(self, xchunk=0, wz=0, use_generic=False):
-        check(lib().fdw_set_tuning(self._h, xchunk, wz, int(use_generic)))
+    def set_tuning(self, xchunk=0, wz=0, use_generic=False, prefetch=0, force_edge=False):
+        check(lib().fdw_set_tuning(self._h, xchunk, wz, int(use_generic), prefetch, int(force_edge)))
 
     def selftest(self):
         check(lib().fdw_selftest(self._h))

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -56,7 +57,7 @@ struct fdw_ctx {
     // local-row translations
     int lap_x0 = 0, lap_x1 = 0, lap_z0 = 0, lap_z1 = 0;     // RTM modes
     int slap_x0 = 0, slap_x1 = 0, slap_z0 = 0, slap_z1 = 0; // stencil program (full interior)
-    int upd_x1 = 0, upd_z1 = 0, tz_x1 = 0;
+    int upd_x1 = 0, upd_z1 = 0, tz_x1 = 0, xt_lo = 0, xt_hi = 0;
     float dt2 = 0.f;
     float cx[FDW_MAX_ORDER + 1]{}, cz[FDW_MAX_ORDER + 1]{};    // RTM weights (C libm variant unless coef_cxx)
     std::vector<float> taper_x, taper_z, txfac;
@@ -68,7 +69,7 @@ struct fdw_ctx {
     float *d_v2 = nullptr, *d_img = nullptr, *d_srce = nullptr, *d_dobs = nullptr;
     size_t srce_cap = 0, dobs_cap = 0;
     // tuning
-    int xchunk = 0, wz = 0, use_generic = 0;
+    int xchunk = 0, wz = 0, use_generic = 0, prefetch = 0, force_edge = 0;
 };
 
 static size_t field_elems(const fdw_ctx* c) { return (size_t)c->nxl * (size_t)c->pitch; }
@@ -170,6 +171,10 @@ extern "C" int fdw_create_slab(const fdw_params* prm, const fdw_slab* slab, int 
     c->nx = prm->nxe - 2 * prm->nxb;
     c->nz = prm->nze - 2 * prm->nzb;
     c->pitch = ((prm->nze + 63) / 64) * 64;  // 256-B aligned rows: every lane's float4 is aligned
+    if (const char* pad = getenv("FDW_PITCH_PAD")) {   // experiment knob: extra floats per row (multiple of 4)
+        const int extra = atoi(pad);
+        if (extra > 0 && extra % 4 == 0) c->pitch += extra;
+    }
 
     // launch extents, R:185-195 (the int assignment truncates before ceil)
     if (prm->compat) {
@@ -196,6 +201,9 @@ extern "C" int fdw_create_slab(const fdw_params* prm, const fdw_slab* slab, int 
     c->upd_x1 = std::max(0, std::min(c->nxl, c->xlim - xo));
     c->upd_z1 = c->zlim;
     c->tz_x1 = c->upd_x1;
+    // rows outside [xt_lo, xt_hi) carry an x damping factor or miss the z factor (corner tiles)
+    c->xt_lo = std::max(0, std::min(c->nxl, prm->nxb - xo));
+    c->xt_hi = std::max(c->xt_lo, std::min(c->nxl, std::min(prm->nxe - prm->nxb, c->xlim) - xo));
 
     // derived constants, R:203-217 (double quotient narrowed to float; float*float scaling)
     const float dx2inv = (1. / prm->dx) * (1. / prm->dx);
@@ -266,6 +274,10 @@ extern "C" void fdw_destroy(fdw_ctx* c)
 // ------------------------------------------------------------------------------------------------
 // launch geometry + one step
 // ------------------------------------------------------------------------------------------------
+// ring size of the register-ring kernel for (half order, prefetch) -- must match RingGeom in fdw_kernels.hip
+static int ring_rows(int h, int pf) { return ((2 * h + pf + pf - 1) / pf) * pf; }
+static int effective_prefetch(const fdw_ctx* c) { return (c->h == 4 && c->prefetch >= 1 && c->prefetch <= 3) ? c->prefetch : 2; }
+
 static void fill_geometry(const fdw_ctx* c, StepArgs& a, int rows)
 {
     const int nstrips = (c->pitch + 255) / 256;
@@ -273,8 +285,17 @@ static void fill_geometry(const fdw_ctx* c, StepArgs& a, int rows)
     if (wz != 1 && wz != 2 && wz != 4) wz = nstrips >= 4 ? 4 : (nstrips >= 2 ? 2 : 1);
     int xchunk = c->xchunk;
     if (xchunk <= 0) {
-        // aim at ~16 waves per CU on 256 CUs; never less than 8 rows (window refill is 2H rows)
-        const long want = ((long)rows * nstrips + 4095) / 4096;
+        // All waves of a launch should fit the chip in a whole number of rounds: 256 CUs x 16 waves
+        // (4 per SIMD at <=128 VGPRs).  A launch with 1.07 rounds of waves takes as long as one with 2.
+        // Prefer ONE round of fat waves (least x-halo re-read: 2H rows per chunk); fall back to smaller
+        // chunks only for grids too small to fill the chip, never below 8 rows.
+        const long slots = 4096;
+        const long per_strip = std::max<long>(slots / nstrips, 1);          // chunks per strip in one round
+        long want = (rows + per_strip - 1) / per_strip;                     // rows per chunk for one round
+        if (want > 128) {                                                    // several rounds: keep chunks moderate
+            const long rounds = (want + 127) / 128;
+            want = (rows + per_strip * rounds - 1) / (per_strip * rounds);
+        }
         xchunk = (int)std::min<long>(std::max<long>(want, 8), 256);
     }
     a.xchunk = xchunk;
@@ -307,7 +328,7 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
     a.lap_x0 = lap ? c->slap_x0 : c->lap_x0; a.lap_x1 = lap ? c->slap_x1 : c->lap_x1;
     a.lap_z0 = lap ? c->slap_z0 : c->lap_z0; a.lap_z1 = lap ? c->slap_z1 : c->lap_z1;
     a.upd_z1 = c->upd_z1;
-    a.ztap = c->ztap; a.tz_x1 = c->tz_x1;
+    a.ztap = c->ztap; a.tz_x1 = c->tz_x1; a.xt_lo = c->xt_lo; a.xt_hi = c->xt_hi;
     a.pp_twice = pp_twice ? 1 : 0;
     a.inj_x = -1; a.inj_z = inj_z; a.inj_n = 0;
     if (mode == FDW_MODE_FWD && d_inj && inj_x_global >= 0) {
@@ -334,7 +355,7 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
     hipError_t e;
     if (c->h <= kMaxFastHalfOrder && !c->use_generic) {
         fill_geometry(c, a, a.r1 - a.r0);
-        e = launch_step_fast(a, c->h, mode, s);
+        e = launch_step_fast(a, c->h, mode, effective_prefetch(c), s);
     } else {
         e = launch_step_generic(a, c->h, mode, s);
     }
@@ -599,13 +620,16 @@ extern "C" int fdw_shot(fdw_ctx* c, const float* v2, int sx, int sz, int gz, con
 // ------------------------------------------------------------------------------------------------
 // tuning / introspection
 // ------------------------------------------------------------------------------------------------
-extern "C" int fdw_set_tuning(fdw_ctx* c, int xchunk, int wz, int use_generic)
+extern "C" int fdw_set_tuning(fdw_ctx* c, int xchunk, int wz, int use_generic, int prefetch, int force_edge)
 {
     if (!c) return fail(FDW_EINVAL, "ctx is NULL");
-    if (xchunk < 0 || (wz != 0 && wz != 1 && wz != 2 && wz != 4)) return fail(FDW_EINVAL, "bad tuning xchunk=%d wz=%d", xchunk, wz);
+    if (xchunk < 0 || (wz != 0 && wz != 1 && wz != 2 && wz != 4) || prefetch < 0 || prefetch > 3)
+        return fail(FDW_EINVAL, "bad tuning xchunk=%d wz=%d prefetch=%d", xchunk, wz, prefetch);
     c->xchunk = xchunk;
     c->wz = wz;
     c->use_generic = use_generic ? 1 : 0;
+    c->prefetch = prefetch;
+    c->force_edge = force_edge ? 1 : 0;
     return FDW_OK;
 }
 

@@ -32,6 +32,7 @@ struct StepArgs {
     int lap_z0, lap_z1;
     int upd_z1;            // columns >= upd_z1 keep their old value (reference launch extent)
     int ztap, tz_x1;       // damped strip: z < ztap; rows < tz_x1 get the z factor
+    int xt_lo, xt_hi;      // rows in [xt_lo, xt_hi) have txfac == 1 and get the z factor (the common case)
     int pp_twice;          // pp owes the previous step's T() (all steps but the first after an upload)
     int inj_x, inj_z, inj_n;
     int xchunk, wz, nzblk, nblk, nper;  // launch geometry (fast kernel)
@@ -39,7 +40,7 @@ struct StepArgs {
     float cx[2 * kMaxFastHalfOrder + 1], cz[2 * kMaxFastHalfOrder + 1];
 };
 
-hipError_t launch_step_fast(const StepArgs& a, int half_order, int mode, hipStream_t s);
+hipError_t launch_step_fast(const StepArgs& a, int half_order, int mode, int prefetch, hipStream_t s);
 hipError_t launch_step_generic(const StepArgs& a, int half_order, int mode, hipStream_t s);
 hipError_t launch_taper_finalize(float* f, const float* taperz, const float* txfac, int pitch, int nxl, int ztap,
                                  int tz_x1, hipStream_t s);

@@ -7,15 +7,18 @@
 //
 //   * lanes run along z (the contiguous axis); a lane owns one float4 (4 consecutive z), a wave owns
 //     a 256-wide z strip -> every global access is a 1 KiB coalesced global_load/store_dwordx4;
-//   * a wave marches along x over `xchunk` rows keeping the 2H+1 rows of p it needs in REGISTERS
-//     (x taps never touch memory twice inside a chunk);
+//   * a wave marches along x over `xchunk` rows keeping the rows of p it needs in a REGISTER ring
+//     (2H+1 stencil rows + look-ahead rows that are still in flight), so x taps never touch memory
+//     twice inside a chunk and HBM latency is covered by explicit software prefetch, not occupancy;
 //   * z taps come from the two neighbouring lanes by DPP wave shifts (v_mov_b32_dpp wave_shr:1 /
 //     wave_shl:1) of the centre row; only lanes 0 and 63 fetch a 16-B strip halo, in one
 //     exec-masked load whose result is the DPP `old` operand (so the merge is free);
 //   * taper, Laplacian, leap-frog update, point-source / receiver injection and the imaging
 //     condition are fused: p, pp, v2 are read once and pp written once = 16 B/point/step
 //     (+12 B/point for the imaging epilogue).  No LDS, no MFMA: the stencil is HBM-bound
-//     (about 2.5 flop/B), the register window is the cheapest tile there is.
+//     (about 2.5 flop/B), the register ring is the cheapest tile there is.
+//   * every wave picks one of two code paths: waves whose whole tile is interior run a mask-free
+//     body; waves touching a grid edge, the damped strip or an injection point run the general body.
 //
 // Arithmetic is the reference's, operation for operation, so results are IEEE-identical to the
 // no-FMA CUDA build (nvcc --fmad=false --ftz=false, Makefile:4): two fp32 accumulators summed
@@ -29,6 +32,9 @@
 // sequence of fp32 multiplies the reference performs.  The host owes one T() when it finally
 // downloads d_p (fdw_taper_finalize_kernel).
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
+
 #include "fdw_kernels.h"
 
 #pragma clang fp contract(off)
@@ -36,11 +42,16 @@
 namespace fdw {
 
 // ------------------------------------------------------------------------------------------------
-// cross-lane helpers (wave64)
+// small helpers
 // ------------------------------------------------------------------------------------------------
 // lane n <- lane n-1; lane 0 keeps `old` (its strip halo).  DPP_WF_SR1 = 0x138.
 __device__ __forceinline__ float wave_shr1(float src, float old)
 {
+#if (defined(FDW_ABLATE) && FDW_ABLATE == 8) || (FDW_ABL_BITS & 8)
+    return src + old;
+#elif defined(FDW_ABLATE) && FDW_ABLATE == 9
+    { const float t = __shfl_up(src, 1, 64); return (threadIdx.x & 63) == 0 ? old : t; }
+#endif
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
                                                                    __builtin_bit_cast(int, src),
                                                                    0x138, 0xf, 0xf, false));
@@ -48,10 +59,22 @@ __device__ __forceinline__ float wave_shr1(float src, float old)
 // lane n <- lane n+1; lane 63 keeps `old`.  DPP_WF_SL1 = 0x130.
 __device__ __forceinline__ float wave_shl1(float src, float old)
 {
+#if (defined(FDW_ABLATE) && FDW_ABLATE == 8) || (FDW_ABL_BITS & 8)
+    return src - old;
+#elif defined(FDW_ABLATE) && FDW_ABLATE == 9
+    { const float t = __shfl_down(src, 1, 64); return (threadIdx.x & 63) == 63 ? old : t; }
+#endif
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
                                                                    __builtin_bit_cast(int, src),
                                                                    0x130, 0xf, 0xf, false));
 }
+
+#ifndef FDW_ABLATE
+#define FDW_ABLATE 0   // timing experiments only (scripts/build_ablations.sh)
+#endif
+#ifndef FDW_ABL_BITS
+#define FDW_ABL_BITS 0  // bitmask form: 1 f32 update, 2 no halo load, 4 no store, 8 no DPP, 16 trivial Laplacian
+#endif
 
 struct f4 {
     float v[4];
@@ -63,16 +86,26 @@ __device__ __forceinline__ f4 f4_zero()
     r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.0f;
     return r;
 }
-__device__ __forceinline__ f4 f4_load(const float* p)
+// scalar (wave-uniform) row base + 32-bit per-lane byte offset: global_load saddr + voffset form
+__device__ __forceinline__ f4 f4_load(const float* row, unsigned voff_bytes)
 {
-    const float4 t = *reinterpret_cast<const float4*>(p);
+    const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(row) + voff_bytes);
     f4 r;
     r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
     return r;
 }
-__device__ __forceinline__ void f4_store(float* p, const f4& a)
+__device__ __forceinline__ void f4_store(float* row, unsigned voff_bytes, const f4& a)
 {
-    *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(row) + voff_bytes) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
 }
 
 // one application of the reference's taper to a value: (v * taperz[j]) * taperx[i]  (R:103-114).
@@ -84,19 +117,293 @@ __device__ __forceinline__ float taper1(float v, float tz, bool zone, bool rowtz
     return (v * fz) * fx;
 }
 
+// The arithmetic of one grid point, exactly as kernel_lap + kernel_time spell it (R:66-72, R:89).
+//   W    12 consecutive z values of the centre row: W[4+e] is the point itself
+//   col  the 2H+1 x taps of this point, oldest row first
+template <int H>
+__device__ __forceinline__ float laplacian_pt(const float* W, int e, const float (&col)[2 * H + 1], const float* cx,
+                                              const float* cz)
+{
+    float acmz = 0.0f, acmx = 0.0f;
+#if FDW_ABLATE == 11 || (FDW_ABL_BITS & 16)
+    return W[e] + W[8 + e] + col[0] + col[2 * H];   // keep every input alive, almost no arithmetic
+#endif
+#pragma unroll
+    for (int io = 0; io <= 2 * H; ++io) {
+        acmz = acmz + W[4 + e - H + io] * cz[io];
+        acmx = acmx + col[io] * cx[io];
+    }
+    return acmz + acmx;
+}
+__device__ __forceinline__ float leapfrog_pt(float p, float pp, float v2, float dt2, float lap)
+{
+    const float prod = (v2 * dt2) * lap;
+#if FDW_ABLATE == 1 || (FDW_ABL_BITS & 1)
+    return (2.0f * p - pp) + prod;
+#endif
+    const double d = 2.0 * (double)p - (double)pp + (double)prod;
+    return (float)d;
+}
+
+// ring geometry: PF rows of pointwise look-ahead (pp, v2, halo, ...); the p ring holds R rows,
+// R a multiple of PF (so queue slots are compile-time constants) and >= 2H+PF.
+template <int H, int PF>
+struct RingGeom {
+    static constexpr int NW = 2 * H + 1;
+    static constexpr int R = ((2 * H + PF + PF - 1) / PF) * PF;
+    static constexpr int LOOK = R - 2 * H;   // rows of p look-ahead
+};
+
+// wave-uniform table read through the scalar cache (s_load_dword, counted by lgkmcnt, so it never
+// disturbs the vmcnt bookkeeping of the streaming loads).  Only for tables no kernel writes.
+__device__ __forceinline__ float sload(const float* p, int i)
+{
+    typedef const float __attribute__((address_space(4))) * cptr;
+    return ((cptr)p)[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // fused step kernel
 //   H       half order (1..4)
-//   TAPER   apply the lazy top-strip damping to p / pp on load
+//   TAPER   apply the lazy top-strip damping to p / pp
 //   INJ     0 none, 1 point source (kernel_src), 2 receiver row (kernel_sism)
 //   IMG     img += psrc * pp_new epilogue (kernel_img)
 //   LAPONLY store the Laplacian itself into a.pp (stencil_code path, S:110-135); no update
+//   PF      software prefetch distance in rows
 // block = 256 threads = 4 independent waves (no LDS, no barrier).
+//
+// ONE code path for every tile.  Every global load of the march is unconditional (addresses are
+// clamped into the slab instead of being predicated), so the compiler's s_waitcnt bookkeeping stays
+// exact and the look-ahead loads really stay in flight.  Whatever a clamped load brings in only ever
+// reaches outputs that the column / row masks zero: rows outside the slab are taps of rows whose
+// Laplacian is masked (lap_x0 >= H, lap_x1 <= nxl-H), columns outside the grid are taps of columns
+// >= nze-H.  Edge handling (masks, damping, injection) is wave-uniform branches around VALU / scalar
+// loads only.
 // ------------------------------------------------------------------------------------------------
-template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY>
+template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF>
+__device__ __forceinline__ void march(const StepArgs& a, const int lane, const int zs, const int xa, const int xe)
+{
+    using G = RingGeom<H, PF>;
+    constexpr int NW = G::NW, R = G::R, LOOK = G::LOOK;
+#if FDW_ABLATE == 10
+    const size_t pitch = 0;   // every row aliases row 0: loads become L1 hits -> pure issue/VALU time
+#else
+    const size_t pitch = (size_t)a.pitch;
+#endif
+    const int z0 = zs + lane * 4;
+    const bool partial = (zs + 256 > a.pitch);              // wave-uniform: last strip of a ragged row
+    const bool act = z0 < a.pitch;                          // pitch % 4 == 0: a float4 never straddles a row end
+    const unsigned voff = (unsigned)min(z0, a.pitch - 4) * 4u;
+    // strip halo in ONE load by all lanes: lane 0 fetches the 4 columns left of the strip, every other
+    // lane the 4 columns right of it (a single 16-B piece; only lane 63 consumes it).
+    const unsigned hoff = (unsigned)((lane == 0) ? max(zs - 4, 0) : min(zs + 256, a.pitch - 4)) * 4u;
+    const bool lane_first = (lane == 0), lane_last = (lane == 63);
+    const int rowmax = min(a.nxl, xe + H) - 1;              // last row of p this wave can need
+
+    // wave-uniform classification of the tile
+    const bool zedge = (zs < a.lap_z0) || (zs + 256 > a.lap_z1) || (!LAPONLY && zs + 256 > a.upd_z1);
+    const bool xedge = (xa < a.lap_x0) || (xe > a.lap_x1);
+    const bool wave_tap = TAPER && (zs - 4 < a.ztap);
+    const bool xtap = wave_tap && ((xa - H < a.xt_lo) || (xe + H > a.xt_hi));   // rows with an x factor / no z factor
+    bool inj_here = false;
+    if (INJ == 1) inj_here = (a.inj_x >= xa) && (a.inj_x < xe) && (a.inj_z >= zs) && (a.inj_z < zs + 256);
+    if (INJ == 2) inj_here = (a.inj_z >= zs) && (a.inj_z < zs + 256) && (a.inj_x < xe) && (a.inj_x + a.inj_n > xa);
+    const float inj_src = (INJ == 1 && inj_here) ? sload(a.inj, 0) : 0.0f;
+
+    // per-lane column masks and damping factors
+    bool mlap[4], mupd[4], znc[4], znh[4], ihit[4];
+    float tzc[4], tzh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int z = z0 + e;
+        mlap[e] = (z >= a.lap_z0) && (z < a.lap_z1);
+        mupd[e] = z < a.upd_z1;
+        ihit[e] = (z == a.inj_z);
+        znc[e] = znh[e] = false;
+        tzc[e] = tzh[e] = 1.0f;
+    }
+    if (wave_tap) {
+        const int hz = (lane == 0) ? zs - 4 : zs + 256;     // true (unclamped) column of this lane's halo piece
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int zc = z0 + e, zh = hz + e;
+            znc[e] = zc < a.ztap;
+            znh[e] = (zh >= 0) && (zh < a.ztap);
+            if (znc[e]) tzc[e] = a.taperz[zc];
+            if (znh[e]) tzh[e] = a.taperz[zh];
+        }
+    }
+    // one application of the reference's damping to a row held in registers (R:103-114)
+    auto taper_row = [&](f4& v, const float* tz, const bool* zone, int row) {
+        if (!xtap) {   // common case: no x factor on these rows, every row gets the z factor; *1.0f is exact
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = v.v[e] * tz[e];
+        } else {
+            const int rc = min(max(row, 0), a.nxl - 1);
+            const float txr = sload(a.txfac, rc);
+            const bool rowtz = row < a.tz_x1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = taper1(v.v[e], tz[e], zone[e], rowtz, txr);
+        }
+    };
+
+    // ---- loaders: unconditional, clamped --------------------------------------------------------
+    auto load_p = [&](int row) -> f4 { return f4_load(a.p + (size_t)min(max(row, 0), rowmax) * pitch, voff); };
+    auto load_halo = [&](int row) -> f4 {
+#if FDW_ABLATE == 2 || (FDW_ABL_BITS & 2)
+        return f4_zero();
+#endif
+        return f4_load(a.p + (size_t)row * pitch, hoff);
+    };
+    auto load_plain = [&](const float* base, int row) -> f4 { return f4_load(base + (size_t)row * pitch, voff); };
+
+    // ---- prologue: ring rows xa-H .. xa-H+R-1; pointwise rows xa .. xa+PF-1 --------------------
+    // Issue order matters: the loop-header s_waitcnt is the stricter of (prologue state, end-of-turn
+    // state).  Issuing the look-ahead loads in the order the steady state would have issued them
+    // ("virtual steps" -LOOK..-1) makes the two states agree, so no turn starts with a pipeline drain.
+    f4 ring[R];
+    f4 qhal[PF], qpp[PF], qv2[PF], qps[PF], qim[PF];
+    constexpr int NV = LOOK > PF ? LOOK : PF;
+    static_for<2 * H>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        ring[k] = load_p(xa - H + k);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    static_for<NV>([&](auto JJ) {
+        constexpr int j = decltype(JJ)::value - NV;   // virtual step -NV .. -1
+        if constexpr (j >= -LOOK) ring[j + 2 * H + LOOK] = load_p(xa + j + H + LOOK);
+        if constexpr (j >= -PF) {
+            constexpr int m = j + PF;
+            const int row = min(xa + m, xe - 1);
+            qhal[m] = load_halo(row);
+            if constexpr (!LAPONLY) {
+                qpp[m] = load_plain(a.pp, row);
+                qv2[m] = load_plain(a.v2, row);
+            }
+            if constexpr (IMG) {
+                qps[m] = load_plain(a.psrc, row);
+                qim[m] = load_plain(a.img, row);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    if (wave_tap) {   // the first 2H window rows never "enter" the window during the march: damp them here
+        static_for<2 * H>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            taper_row(ring[k], tzc, znc, xa - H + k);
+        });
+    }
+
+    // One row of the march.  GUARD=false: the row is known to exist; GUARD=true: wave-uniform test.
+    auto row_step = [&](const int rb, auto UU, auto GG) {
+        constexpr int U = decltype(UU)::value;
+        constexpr bool GUARD = decltype(GG)::value;
+        constexpr int Q = U % PF;          // pointwise queue slot of this row (R % PF == 0)
+        const int r = rb + U;
+        if (!GUARD || r < xe) {
+            // ---- damping of what enters the computation this step -----------------------------
+            f4 hal = qhal[Q];
+            f4 ppt = qpp[Q];
+            if (wave_tap) {
+                taper_row(ring[(U + 2 * H) % R], tzc, znc, r + H);   // row r+H enters the window
+                taper_row(hal, tzh, znh, r);
+                if constexpr (!LAPONLY) {
+                    taper_row(ppt, tzc, znc, r);
+                    if (a.pp_twice) taper_row(ppt, tzc, znc, r);
+                }
+            }
+            // ---- z neighbours from the adjacent lanes (ds_bpermute), strip halo at the ends ----
+            const f4 c = ring[(U + H) % R];
+            float W[12];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#if FDW_ABL_BITS & 8
+                W[e] = c.v[e] + hal.v[e];
+                W[8 + e] = c.v[e] - hal.v[e];
+#else
+                const float up = __shfl_up(c.v[e], 1, 64), dn = __shfl_down(c.v[e], 1, 64);
+                W[e] = lane_first ? hal.v[e] : up;
+                W[8 + e] = lane_last ? hal.v[e] : dn;
+#endif
+                W[4 + e] = c.v[e];
+            }
+            const bool rowok = (r >= a.lap_x0) && (r < a.lap_x1);
+            f4 res, imr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float col[NW];
+#pragma unroll
+                for (int io = 0; io < NW; ++io) col[io] = ring[(U + io) % R].v[e];
+                float lap = laplacian_pt<H>(W, e, col, a.cx, a.cz);
+                if (zedge || xedge) lap = (rowok && mlap[e]) ? lap : 0.0f;
+                float out;
+                if constexpr (LAPONLY) {
+                    out = lap;
+                } else {
+                    const float upd = leapfrog_pt(c.v[e], ppt.v[e], qv2[Q].v[e], a.dt2, lap);
+                    out = upd;
+                    if (zedge) out = mupd[e] ? upd : ppt.v[e];
+                }
+                res.v[e] = out;
+            }
+            if constexpr (INJ != 0) {
+                if (inj_here) {   // wave-uniform, rare
+                    const bool injrow = (INJ == 1) ? (r == a.inj_x) : ((r >= a.inj_x) && (r < a.inj_x + a.inj_n));
+                    if (injrow) {
+                        const float injv = (INJ == 1) ? inj_src : sload(a.inj, r - a.inj_x);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) res.v[e] = ihit[e] ? res.v[e] + injv : res.v[e];
+                    }
+                }
+            }
+            if constexpr (IMG) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) imr.v[e] = qim[Q].v[e] + qps[Q].v[e] * res.v[e];
+            }
+#if FDW_ABLATE == 4 || FDW_ABLATE == 10 || (FDW_ABL_BITS & 4)
+            if (res.v[0] == 123.456f)
+#endif
+            if (!partial) {
+                f4_store(a.pp + (size_t)r * pitch, voff, res);
+                if constexpr (IMG) f4_store(a.img + (size_t)r * pitch, voff, imr);
+            } else if (act) {
+                f4_store(a.pp + (size_t)r * pitch, voff, res);
+                if constexpr (IMG) f4_store(a.img + (size_t)r * pitch, voff, imr);
+            }
+
+            // ---- refill the slots this row just freed (look-ahead loads) ----------------------
+            ring[U] = load_p(r - H + R);
+            {
+                const int nr = min(r + PF, xe - 1);
+                qhal[Q] = load_halo(nr);
+                if constexpr (!LAPONLY) {
+                    qpp[Q] = load_plain(a.pp, nr);
+                    qv2[Q] = load_plain(a.v2, nr);
+                }
+                if constexpr (IMG) {
+                    qps[Q] = load_plain(a.psrc, nr);
+                    qim[Q] = load_plain(a.img, nr);
+                }
+            }
+        }
+        // keep the look-ahead loads where they were issued: without this the machine scheduler
+        // sinks each load to one row before its first use to save registers, which turns the
+        // software prefetch into a load-use stall every row
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    int rb = xa;
+    // bulk: whole turns of the ring, no tests, exact s_waitcnt bookkeeping
+    for (; rb + R <= xe; rb += R)
+        static_for<R>([&](auto UU) { row_step(rb, UU, std::false_type{}); });
+    // remaining rows (< R)
+    if (rb < xe)
+        static_for<R>([&](auto UU) { row_step(rb, UU, std::true_type{}); });
+}
+
+template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF>
 __global__ __launch_bounds__(256) void fdw_step_kernel(const StepArgs a)
 {
-    constexpr int NW = 2 * H + 1;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -116,183 +423,13 @@ __global__ __launch_bounds__(256) void fdw_step_kernel(const StepArgs a)
     const int xa = a.r0 + chunk * a.xchunk;
     const int xe = min(xa + a.xchunk, a.r1);
     if (xa >= xe) return;
-
-    const int z0 = zs + lane * 4;
-    const bool act = z0 < a.pitch;    // pitch is a multiple of 4: a float4 never straddles a row end
-    // strip halo: lane 0 fetches the 4 columns left of the strip, lane 63 the 4 columns right of it
-    const int hz = (lane == 0) ? z0 - 4 : z0 + 4;
-    const bool hact = (lane == 0) ? (zs >= 4) : (lane == 63 && hz < a.pitch);
-
-    // per-lane damping factors along z (constant over the march)
-    const bool wave_tap = TAPER && (zs - 4 < a.ztap);
-    float tzc[4], tzh[4];
-    bool znc[4], znh[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        tzc[e] = tzh[e] = 1.0f;
-        znc[e] = znh[e] = false;
-    }
-    if (wave_tap) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int zc = z0 + e, zh = hz + e;
-            znc[e] = zc < a.ztap;
-            znh[e] = hact && zh < a.ztap;
-            if (znc[e]) tzc[e] = a.taperz[zc];
-            if (znh[e]) tzh[e] = a.taperz[zh];
-        }
-    }
-
-    // row loaders -------------------------------------------------------------------------------
-    auto rowptr = [&](const float* base, int row) -> const float* {
-        return base + (size_t)row * (size_t)a.pitch;
-    };
-    // a row of p for the register window, damped once when TAPER
-    auto load_p = [&](int row) -> f4 {
-        f4 v = f4_zero();
-        if (row >= 0 && row < a.nxl) {
-            if (act) v = f4_load(rowptr(a.p, row) + z0);
-            if (wave_tap) {
-                const float txr = a.txfac[row];
-                const bool rowtz = row < a.tz_x1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v.v[e] = taper1(v.v[e], tzc[e], znc[e], rowtz, txr);
-            }
-        }
-        return v;
-    };
-    // strip halo of the centre row (only lanes 0 / 63 hold data), damped once when TAPER
-    auto load_halo = [&](int row) -> f4 {
-        f4 v = f4_zero();
-        if (hact) v = f4_load(rowptr(a.p, row) + hz);
-        if (wave_tap) {
-            const float txr = a.txfac[row];
-            const bool rowtz = row < a.tz_x1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v.v[e] = taper1(v.v[e], tzh[e], znh[e], rowtz, txr);
-        }
-        return v;
-    };
-    auto load_plain = [&](const float* base, int row) -> f4 {
-        f4 v = f4_zero();
-        if (act) v = f4_load(rowptr(base, row) + z0);
-        return v;
-    };
-
-    // prologue: fill the window with rows xa-H .. xa+H ------------------------------------------
-    f4 win[NW];
-#pragma unroll
-    for (int k = 0; k < NW; ++k) win[k] = load_p(xa - H + k);
-    f4 hal = load_halo(xa);
-    f4 cpp = f4_zero(), cv2 = f4_zero(), cps = f4_zero(), cim = f4_zero();
-    if (!LAPONLY) {
-        cpp = load_plain(a.pp, xa);
-        cv2 = load_plain(a.v2, xa);
-    }
-    if (IMG) {
-        cps = load_plain(a.psrc, xa);
-        cim = load_plain(a.img, xa);
-    }
-
-    for (int rb = xa; rb < xe; rb += NW) {
-#pragma unroll
-        for (int u = 0; u < NW; ++u) {
-            const int r = rb + u;
-            if (r < xe) {
-                // ---- prefetch everything the NEXT row needs before touching this one ----------
-                const bool more = (r + 1 < xe);
-                f4 nxt = load_p(r + H + 1);
-                f4 nhal = f4_zero(), npp = f4_zero(), nv2 = f4_zero(), nps = f4_zero(), nim = f4_zero();
-                if (more) {
-                    nhal = load_halo(r + 1);
-                    if (!LAPONLY) {
-                        npp = load_plain(a.pp, r + 1);
-                        nv2 = load_plain(a.v2, r + 1);
-                    }
-                    if (IMG) {
-                        nps = load_plain(a.psrc, r + 1);
-                        nim = load_plain(a.img, r + 1);
-                    }
-                }
-
-                // ---- this row ------------------------------------------------------------------
-                const f4 c = win[(u + H) % NW];
-                float W[12];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    W[e] = wave_shr1(c.v[e], hal.v[e]);
-                    W[4 + e] = c.v[e];
-                    W[8 + e] = wave_shl1(c.v[e], hal.v[e]);
-                }
-                f4 ppt = cpp;
-                if (!LAPONLY && wave_tap) {
-                    const float txr = a.txfac[r];
-                    const bool rowtz = r < a.tz_x1;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float t = taper1(ppt.v[e], tzc[e], znc[e], rowtz, txr);
-                        if (a.pp_twice) t = taper1(t, tzc[e], znc[e], rowtz, txr);
-                        ppt.v[e] = t;
-                    }
-                }
-                const bool lapx = (r >= a.lap_x0) && (r < a.lap_x1);
-                float injv = 0.0f;
-                bool injrow = false;
-                if (INJ == 1) {
-                    injrow = (r == a.inj_x);
-                    if (injrow) injv = a.inj[0];
-                } else if (INJ == 2) {
-                    injrow = (r >= a.inj_x) && (r < a.inj_x + a.inj_n);
-                    if (injrow) injv = a.inj[r - a.inj_x];
-                }
-                f4 res, imr;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int z = z0 + e;
-                    float acmz = 0.0f, acmx = 0.0f;
-#pragma unroll
-                    for (int io = 0; io < NW; ++io) {
-                        acmz = acmz + W[4 + e - H + io] * a.cz[io];
-                        acmx = acmx + win[(u + io) % NW].v[e] * a.cx[io];
-                    }
-                    float lap = acmz + acmx;
-                    const bool inl = lapx && (z >= a.lap_z0) && (z < a.lap_z1);
-                    lap = inl ? lap : 0.0f;
-                    float out;
-                    if (LAPONLY) {
-                        out = lap;
-                    } else {
-                        const float prod = (cv2.v[e] * a.dt2) * lap;
-                        const double d = 2.0 * (double)c.v[e] - (double)ppt.v[e] + (double)prod;
-                        out = (z < a.upd_z1) ? (float)d : ppt.v[e];
-                        if (INJ != 0) {
-                            if (injrow && z == a.inj_z) out = out + injv;
-                        }
-                    }
-                    res.v[e] = out;
-                    if (IMG) imr.v[e] = cim.v[e] + cps.v[e] * out;
-                }
-                if (act) {
-                    f4_store(const_cast<float*>(rowptr(a.pp, r)) + z0, res);
-                    if (IMG) f4_store(const_cast<float*>(rowptr(a.img, r)) + z0, imr);
-                }
-
-                // ---- rotate --------------------------------------------------------------------
-                win[u] = nxt;
-                hal = nhal;
-                cpp = npp;
-                cv2 = nv2;
-                cps = nps;
-                cim = nim;
-            }
-        }
-    }
+    march<H, TAPER, INJ, IMG, LAPONLY, PF>(a, lane, zs, xa, xe);
 }
 
 // ------------------------------------------------------------------------------------------------
 // generic-order kernel: any even order up to FDW_MAX_ORDER, one thread per point, every tap from
 // global memory (L1/L2 absorb the reuse).  Same arithmetic, same lazy-taper rules; used for orders
-// the register-window kernel is not instantiated for, and as an independent cross-check of it.
+// the register-ring kernel is not instantiated for, and as an independent cross-check of it.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float generic_p(const StepArgs& a, int row, int z, bool taper)
 {
@@ -329,9 +466,8 @@ __global__ __launch_bounds__(256) void fdw_generic_kernel(const StepArgs a, int 
             ppv = taper1(ppv, tz, true, rowtz, txr);
             if (a.pp_twice) ppv = taper1(ppv, tz, true, rowtz, txr);
         }
-        const float prod = (a.v2[k] * a.dt2) * lap;
-        const double d = 2.0 * (double)pc - (double)ppv + (double)prod;
-        out = (z < a.upd_z1) ? (float)d : ppv;
+        const float upd = leapfrog_pt(pc, ppv, a.v2[k], a.dt2, lap);
+        out = (z < a.upd_z1) ? upd : ppv;
         if (injmode == 1) {
             if (r == a.inj_x && z == a.inj_z) out = out + a.inj[0];
         } else if (injmode == 2) {
@@ -369,28 +505,34 @@ __global__ void fdw_dpp_selftest_kernel(const float* src, const float* old, floa
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-template <int H>
-static hipError_t launch_fast_h(const StepArgs& a, int mode, hipStream_t s)
+template <int H, int PF>
+static hipError_t launch_fast_hp(const StepArgs& a, int mode, hipStream_t s)
 {
     const dim3 grid(8 * a.nper), block(256);
     switch (mode) {
-    case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_step_kernel<H, true, 1, false, false>), grid, block, 0, s, a); break;
-    case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_step_kernel<H, false, 0, false, false>), grid, block, 0, s, a); break;
-    case FDW_MODE_RECV:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false>), grid, block, 0, s, a); break;
-    case FDW_MODE_LAP:   hipLaunchKernelGGL((fdw_step_kernel<H, false, 0, false, true>), grid, block, 0, s, a); break;
+    case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_step_kernel<H, true, 1, false, false, PF>), grid, block, 0, s, a); break;
+    case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_step_kernel<H, false, 0, false, false, PF>), grid, block, 0, s, a); break;
+    case FDW_MODE_RECV:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, PF>), grid, block, 0, s, a); break;
+    case FDW_MODE_LAP:   hipLaunchKernelGGL((fdw_step_kernel<H, false, 0, false, true, PF>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_step_fast(const StepArgs& a, int h, int mode, hipStream_t s)
+hipError_t launch_step_fast(const StepArgs& a, int h, int mode, int pf, hipStream_t s)
 {
     if (a.nper <= 0) return hipSuccess;
+    if (h == 4) {
+        switch (pf) {
+        case 1: return launch_fast_hp<4, 1>(a, mode, s);
+        case 3: return launch_fast_hp<4, 3>(a, mode, s);
+        default: return launch_fast_hp<4, 2>(a, mode, s);
+        }
+    }
     switch (h) {
-    case 1: return launch_fast_h<1>(a, mode, s);
-    case 2: return launch_fast_h<2>(a, mode, s);
-    case 3: return launch_fast_h<3>(a, mode, s);
-    case 4: return launch_fast_h<4>(a, mode, s);
+    case 1: return launch_fast_hp<1, 2>(a, mode, s);
+    case 2: return launch_fast_hp<2, 2>(a, mode, s);
+    case 3: return launch_fast_hp<3, 2>(a, mode, s);
     default: return hipErrorInvalidValue;
     }
 }

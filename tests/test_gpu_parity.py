@@ -100,6 +100,51 @@ def test_forward_vs_oracle_bit_exact(case):
     assert PP.any()
 
 
+@pytest.mark.parametrize("prefetch", [1, 2, 3])
+def test_forward_interior_waves_vs_oracle(prefetch):
+    """A grid wide and tall enough that most waves take the mask-free interior body (whole ring turns,
+    strips 1..3), for every prefetch depth, against the oracle and against the all-edge code path."""
+    d = make_deck(150, 1300, 20, 24, 12, seed=21)
+    srce = O.ricker_wavelet(12, d["dt"], 30.0)
+    p0, pp0 = random_fields(d, seed=5, amp=0.1)
+    oP, oPP = mko(d).forward(d["v2"], d["sx"], d["sz"], srce, p0, pp0)
+    ctx = mk(d)
+    for xchunk in (0, 12, 24, 30, 36):
+        for force_edge in (False, True):
+            ctx.set_tuning(xchunk=xchunk, prefetch=prefetch, force_edge=force_edge)
+            P, PP = ctx.forward(d["v2"], d["sx"], d["sz"], srce, p0, pp0)
+            assert_bit_equal(P, oP, f"P pf={prefetch} xchunk={xchunk} edge={force_edge}")
+            assert_bit_equal(PP, oPP, f"PP pf={prefetch} xchunk={xchunk} edge={force_edge}")
+
+
+@pytest.mark.parametrize("order", [2, 4, 6])
+def test_forward_interior_waves_low_orders(order):
+    d = make_deck(90, 1100, 12, 16, 8, seed=order, order=order)
+    srce = O.ricker_wavelet(8, d["dt"], 30.0)
+    p0, pp0 = random_fields(d, seed=6, amp=0.1)
+    oP, oPP = mko(d).forward(d["v2"], d["sx"], d["sz"], srce, p0, pp0)
+    ctx = mk(d)
+    for xchunk in (0, 6, 8, 10, 16):
+        ctx.set_tuning(xchunk=xchunk)
+        P, PP = ctx.forward(d["v2"], d["sx"], d["sz"], srce, p0, pp0)
+        assert_bit_equal(P, oP, f"P order={order} xchunk={xchunk}")
+        assert_bit_equal(PP, oPP, f"PP order={order} xchunk={xchunk}")
+
+
+def test_back_interior_waves_vs_oracle():
+    d = make_deck(120, 1100, 16, 20, 10, seed=8)
+    nx, nz = 120 - 32, 1100 - 40
+    srce = O.ricker_wavelet(10, d["dt"], 30.0)
+    d_obs = np.random.default_rng(3).standard_normal((nx, 10)).astype(np.float32)
+    orc, ctx = mko(d), mk(d)
+    oP, oPP = orc.forward(d["v2"], d["sx"], d["sz"], srce)
+    oimg = orc.back(d["v2"], oP, oPP, d_obs, d["gz"])
+    for xchunk in (0, 10, 20):
+        ctx.set_tuning(xchunk=xchunk)
+        assert_bit_equal(ctx.back(d["v2"], oP, oPP, d_obs, d["gz"]), oimg, f"imloc xchunk={xchunk}")
+        assert_bit_equal(ctx.shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs), oimg, f"shot imloc xchunk={xchunk}")
+
+
 def test_forward_fast_kernel_equals_generic_kernel():
     d = make_deck(140, 600, 20, 24, 40, seed=2)
     srce = O.ricker_wavelet(40, d["dt"], 30.0)
