@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fused 8th-order 2-D acoustic time step (taper + Laplacian + leap-frog + source,
+the body of the reference's fd_forward loop, cuda_reference_RTM/src/fd-code.cu:259-267) on a synthetic
+grid, device resident.  One JSON line on rank 0.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 8192] [--ksteps 4] [--no-cpu-baseline]
+
+N = 1 : the whole grid on one MI355X.
+N > 1 : launched by torch.distributed.run, one rank per GPU; the SAME grid is split into x slabs with
+        deep-halo exchange over RCCL (parallel_finite_difference_computation_amd/decomp.py) -- strong
+        scaling, as BASELINE.json's "RTM domain decomposition, 8192^2 grid, 2->4->8" config asks.
+
+Metric: Gpoints/s = nxe*nze*K / wall (barrier + synchronize on both sides, max over ranks).
+roofline: the step kernel is HBM bound; algorithmic traffic is 16 B/point/step (read p, pp, v2; write
+pp).  `achieved` is measured live with HIP events on the launch stream.
+cpu_baseline: the oracle's fused C loop (same arithmetic), 1 thread, bounded sample, rank 0, N = 1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import parallel_finite_difference_computation_amd as F  # noqa: E402
+from parallel_finite_difference_computation_amd.decomp import HipSlabStepper, SlabForward, SlabGeometry  # noqa: E402
+
+ALGO_BYTES_PER_POINT = 16.0   # read p, pp, v2 + write pp
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+ORDER, NB, FAC, DX, DT, FPEAK = 8, 64, 0.75, 10.0, 1.0e-3, 20.0
+
+
+def synthetic_velocity_rows(n, row0, rows, device):
+    """v(ix,iz) = 1500 + 2500*iz/(nze-1) with a 3 % lateral sinusoid (m/s)."""
+    z = torch.arange(n, device=device, dtype=torch.float32)[None, :]
+    x = torch.arange(row0, row0 + rows, device=device, dtype=torch.float32)[:, None]
+    v = (1500.0 + 2500.0 * z / (n - 1)) * (1.0 + 0.03 * torch.sin(2.0 * np.pi * 8.0 * x / n))
+    return v * v
+
+
+def cpu_baseline(n, seconds_target=12.0):
+    """Oracle's fused loop, one thread, on the same grid size; bounded to ~10-20 s."""
+    from oracle import oracle as O
+    L = O.lib()
+    cx, cz = O.scaled_coefs(ORDER, DX, DX)
+    rng = np.random.default_rng(0)
+    p = (1e-3 * rng.standard_normal((n, n))).astype(np.float32)
+    pp = (1e-3 * rng.standard_normal((n, n))).astype(np.float32)
+    v2 = synthetic_velocity_rows(n, 0, n, "cpu").numpy().astype(np.float32)
+    t0 = time.perf_counter()
+    L.orc_fused_steps(ORDER, n, n, p, pp, v2, cx, cz, DT * DT, 1)
+    one = time.perf_counter() - t0
+    steps = int(max(1, min(40, round(seconds_target / max(one, 1e-3)) - 1)))
+    t0 = time.perf_counter()
+    L.orc_fused_steps(ORDER, n, n, p, pp, v2, cx, cz, DT * DT, steps)
+    dt = time.perf_counter() - t0
+    return {"value": round(n * n * steps / dt / 1e9, 4), "unit": "Gpoints/s", "cores": 1, "kind": "port",
+            "sample": f"{n}x{n} fp32 grid, {steps} fused steps (oracle/fdw_oracle.c orc_fused_steps, gcc -O2 -ffp-contract=off), "
+                      f"single thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--ksteps", type=int, default=4, help="time steps per halo exchange (N > 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no GPU visible (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n, K, W = args.size, args.steps, args.warmup
+    nt = K + W
+    geom = SlabGeometry(rank, world, n, ORDER // 2, args.ksteps if world > 1 else 1)
+    ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank,
+                   slab=(geom.x_off, geom.nxl) if world > 1 else None)
+    pitch = ctx.pitch
+    a = torch.zeros((geom.nxl, pitch), device=dev)
+    b = torch.zeros((geom.nxl, pitch), device=dev)
+    v2 = torch.zeros((geom.nxl, pitch), device=dev)
+    v2[:, :n] = synthetic_velocity_rows(n, geom.x_off, geom.nxl, dev)
+    srce = torch.from_numpy(F.ricker_wavelet(nt, DT, FPEAK)).to(dev)
+    fw = SlabForward(geom, HipSlabStepper(ctx), (a, b), v2, srce, n // 2, n // 2, overlap=not args.no_overlap)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fw.run(W)
+    fw.synchronize()       # also forces torch's lazy creation of both streams outside the timed region
+    sync_all()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(fw.compute)
+    fw.run(K)
+    e1.record(fw.compute)
+    while not e1.query():      # spin until the last step has finished: hipStreamSynchronize sleeps in ms-sized naps
+        pass
+    fw.synchronize()
+    sync_all()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    newest = fw.owned(fw.d_pp)
+    finite = bool(torch.isfinite(newest).all().item()) and float(newest.abs().max().item()) > 0.0
+    if world > 1:
+        f = torch.tensor([1.0 if finite else 0.0], device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        finite = bool(f.item() > 0.5)
+
+    if rank == 0:
+        gpts = n * n * K / wall / 1e9
+        # dominant kernel: the fused step.  At N = 1 one launch updates the whole grid; its average
+        # duration is the event time over K back-to-back launches on the launch stream.
+        pts_per_launch = n * n if world == 1 else None
+        out = {
+            "metric": "Gpoints/s (stencil updates) + achieved HBM GB/s vs peak",
+            "value": round(gpts, 3), "unit": "Gpoints/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(wall * 1e3 / K, 6), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"2D 8th-order acoustic stencil, fused forward step (taper+Laplacian+leap-frog+source), "
+                                   f"{n}x{n} fp32 extended grid, nxb=nzb={NB}, {K} steps"
+                                   + (f", x-slab decomposition over {world} GPUs, {args.ksteps} steps per halo exchange" if world > 1 else ""),
+                       "grid": [n, n], "order": ORDER, "parallelism": f"slab{world}" if world > 1 else "single"},
+            "result_finite_nonzero": finite,
+        }
+        if world == 1:
+            launch_ms = dev_ms / K
+            achieved = ALGO_BYTES_PER_POINT * pts_per_launch / (launch_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                               "kernel": "fdw::fdw_step_kernel<4,true,1,false,false,2>", "launch_us": round(launch_ms * 1e3, 2),
+                               "algorithmic_bytes_per_launch": ALGO_BYTES_PER_POINT * pts_per_launch}
+            traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(traffic_file):   # HBM bytes per launch from the committed rocprofv3 --pmc passes
+                try:
+                    t = json.load(open(traffic_file))
+                    if t.get("size") == n:
+                        out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                except Exception:
+                    pass
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(n)
+        else:
+            out["roofline"] = {"bound": "hbm", "achieved": round(ALGO_BYTES_PER_POINT * n * n * K / wall / 1e9, 1),
+                               "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                               "frac": round(ALGO_BYTES_PER_POINT * n * n * K / wall / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not finite:
+        sys.exit("bench: result is not finite / all zero")
+
+
+if __name__ == "__main__":
+    main()

@@ -388,6 +388,56 @@ void orc_stencil(int order, int nxe, int nze, float dx, float dz, const float *i
     orc_kernel_lap(order, nxe, nze, gx, gz, in, out, cx, cz);
 }
 
+/* One forward iteration (R:260-267 without the pointer swap) on an x-slab of a decomposed grid: the
+ * local arrays hold global rows [x_off, x_off+nxl); rows [r0,r1) (local) are updated, rows
+ * [r0-h, r1+h) are damped in place first (they are exactly the rows this step reads).  The reference
+ * has no decomposition; this is the per-slab restatement used by the CPU (gloo) tests of the halo
+ * exchange logic -- with x_off=0, nxl=nxe, r0=t0=0, r1=t1=nxe it is orc_forward_step. */
+void orc_slab_step(const orc_state *s, int x_off, int nxl, float *p, float *pp, const float *v2, int r0, int r1,
+                   int t0, int t1, int sx_global, int sz, float srce_it)
+{
+    /* [t0,t1): rows damped in place by this call.  A caller that splits one time step into several
+     * row ranges damps every row it will read exactly once (first call), t0>=t1 on the others. */
+    const int h = s->order / 2, nze = s->nze, nxe = s->nxe;
+    int l, j, io;
+    float *lap = (float *)calloc((size_t)nxl * nze, sizeof(float));
+    /* kernel_tapper with its thread extents, in global coordinates (pass 1 taperz, pass 2 taperx) */
+    for (l = t0; l < t1; l++) {
+        int g = x_off + l, gm = nxe - 1 - g;
+        for (j = 0; j < s->ztap && j < s->nzb; j++) {
+            size_t k = (size_t)l * nze + j;
+            if (g < s->xlim) { p[k] *= s->taper_z[j]; pp[k] *= s->taper_z[j]; }
+        }
+        for (j = 0; j < s->ztap && j < s->nzb; j++) {
+            size_t k = (size_t)l * nze + j;
+            if (g < s->nxb && g < s->xlim) { p[k] *= s->taper_x[g]; pp[k] *= s->taper_x[g]; }
+            else if (gm < s->nxb && gm < s->xlim) { p[k] *= s->taper_x[gm]; pp[k] *= s->taper_x[gm]; }
+        }
+    }
+    for (l = r0; l < r1; l++) {
+        int g = x_off + l;
+        if (g < h || g >= nxe - h || g >= h + s->xlim || l < h || l >= nxl - h) continue;
+        for (j = h; j < nze - h && j < h + s->zlim; j++) {
+            float acmx = 0, acmz = 0;
+            for (io = 0; io <= s->order; io++) {
+                acmz += p[(size_t)l * nze + j + io - h] * s->coefs_z[io];
+                acmx += p[(size_t)(l + io - h) * nze + j] * s->coefs_x[io];
+            }
+            lap[(size_t)l * nze + j] = acmz + acmx;
+        }
+    }
+    for (l = r0; l < r1; l++) {
+        if (x_off + l >= s->xlim) continue;
+        for (j = 0; j < s->zlim; j++) {
+            size_t k = (size_t)l * nze + j;
+            pp[k] = 2. * p[k] - pp[k] + v2[k] * s->dt2 * lap[k];
+        }
+    }
+    l = sx_global - x_off;
+    if (sx_global >= 0 && l >= r0 && l < r1) pp[(size_t)l * nze + sz] += srce_it;
+    free(lap);
+}
+
 /* Fused single-pass form of the forward iteration body used ONLY as the cpu_baseline "port" timing
  * kernel in bench.py (same arithmetic per point as lap+time above, full extents, no taper/source):
  * reads p, pp, v2 and writes pp -- the 16 B/point shape the GPU kernel is priced on. */

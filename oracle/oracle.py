@@ -38,6 +38,7 @@ def lib():
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_fd_forward.argtypes = [C.c_void_p, f32p, f32p, f32p, C.c_int, C.c_int, f32p, C.c_int]
         L.orc_fd_back.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, f32p, C.c_int]
+        L.orc_slab_step.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, f32p, f32p] + [C.c_int] * 6 + [C.c_float]
         L.orc_stencil.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f32p, f32p]
         L.orc_fused_steps.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, C.c_float, C.c_int]
         _LIB = L
@@ -127,6 +128,14 @@ class Oracle:
         lib().orc_fd_forward(self._h, p, pp, np.ascontiguousarray(v2, np.float32), sx, sz,
                              np.ascontiguousarray(srce, np.float32), nsteps)
         return p, pp
+
+    def slab_step(self, x_off, p, pp, v2, r0, r1, sx, sz, srce_it, taper_rows=None):
+        """One forward iteration on rows [r0,r1) of a slab (local arrays, in place).  Tests only.
+        taper_rows: (t0, t1) rows damped in place by this call (default: every local row)."""
+        nxl = p.shape[0]
+        assert p.shape == pp.shape == v2.shape and p.dtype == np.float32 and p.flags.c_contiguous
+        t0, t1 = (0, nxl) if taper_rows is None else taper_rows
+        lib().orc_slab_step(self._h, x_off, nxl, p, pp, v2, r0, r1, t0, t1, sx, sz, srce_it)
 
     def back(self, v2, snap0, snap1, d_obs, gz, imloc=None, nsteps=None):
         """R:290-341.  d_obs is [nx][nt]; returns imloc [nx][nz]."""

@@ -285,18 +285,17 @@ static void fill_geometry(const fdw_ctx* c, StepArgs& a, int rows)
     if (wz != 1 && wz != 2 && wz != 4) wz = nstrips >= 4 ? 4 : (nstrips >= 2 ? 2 : 1);
     int xchunk = c->xchunk;
     if (xchunk <= 0) {
-        // All waves of a launch should fit the chip in a whole number of rounds: 256 CUs x 16 waves
-        // (4 per SIMD at <=128 VGPRs).  A launch with 1.07 rounds of waves takes as long as one with 2.
-        // Prefer ONE round of fat waves (least x-halo re-read: 2H rows per chunk); fall back to smaller
-        // chunks only for grids too small to fill the chip, never below 8 rows.
-        const long slots = 4096;
-        const long per_strip = std::max<long>(slots / nstrips, 1);          // chunks per strip in one round
-        long want = (rows + per_strip - 1) / per_strip;                     // rows per chunk for one round
-        if (want > 128) {                                                    // several rounds: keep chunks moderate
-            const long rounds = (want + 127) / 128;
-            want = (rows + per_strip * rounds - 1) / (per_strip * rounds);
-        }
-        xchunk = (int)std::min<long>(std::max<long>(want, 8), 256);
+        // Measured on MI355X (scripts/probe_step.py, order 8): once every tile runs the same
+        // branch-free body the step time is flat in the chunk length to within run-to-run noise,
+        // with a shallow optimum at short chunks (many waves per CU slot = good balance; the 2H
+        // halo rows a neighbouring chunk re-reads come from L2 / Infinity Cache, not HBM).
+        //   HBM-resident grids (>= 8192^2): one ring turn (10 rows at prefetch 2)
+        //   Infinity-Cache-resident grids (4096^2): 24 rows
+        //   small decks: 8 rows (latency bound; as many waves as possible)
+        const long strip_rows = (long)rows * nstrips;
+        if (strip_rows >= 200000) xchunk = ring_rows(c->h, effective_prefetch(c));
+        else if (strip_rows >= 32768) xchunk = 24;
+        else xchunk = 8;
     }
     a.xchunk = xchunk;
     a.wz = wz;

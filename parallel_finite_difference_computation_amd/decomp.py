@@ -1,0 +1,190 @@
+"""x-slab domain decomposition of the forward time loop across the GPUs of one node.
+
+The reference has no multi-GPU path; its only parallel axis besides shots is
+space.  Rows (x, the slow axis) are split into `world` contiguous slabs, one process per GPU.  A
+ghost row is `pitch` contiguous floats, so a halo is one contiguous block.
+
+Deep halos: with half order h and `ksteps` steps per exchange every interior side carries
+G = h*ksteps ghost rows.  Right after an exchange all local rows are valid; step j of the cycle
+(j = 1..ksteps) can only update rows [h*j, nxl - h*j) on the interior sides, so the valid region
+shrinks by h per step and is exactly the owned rows after ksteps steps.  The redundant work is
+h*(ksteps-1)/2 rows per side per step; in exchange the per-step collective (a 2x128 KiB message on a
+~25 us step, latency bound over xGMI) becomes one 2*G-row message every ksteps steps.
+
+Both time levels travel (leap-frog state is the pair (p, pp)); what is exchanged is the raw memory
+state of the owner's rows, so the "lazy taper" bookkeeping of the kernels (fdw_kernels.hip) stays a
+pure function of (memory, step index) on every rank.  Arithmetic per point is unchanged, hence the
+decomposed result is bit-identical to the single-slab result.
+
+The stepper is pluggable so that the exchange logic can be exercised on CPU (gloo, world_size 2)
+with the oracle as the compute kernel (tests only); the product path uses `HipSlabStepper`.
+"""
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+def slab_bounds(nxe, world):
+    """Owned global row ranges [o0, o1) per rank: as even as possible, multiples of 4 where possible."""
+    base = [(nxe * r) // world for r in range(world + 1)]
+    for r in range(1, world):
+        base[r] = (base[r] // 4) * 4
+    return [(base[r], base[r + 1]) for r in range(world)]
+
+
+@dataclass
+class SlabGeometry:
+    rank: int
+    world: int
+    nxe: int
+    h: int
+    ksteps: int
+
+    def __post_init__(self):
+        self.G = self.h * self.ksteps
+        self.o0, self.o1 = slab_bounds(self.nxe, self.world)[self.rank]
+        self.has_lo = self.rank > 0
+        self.has_hi = self.rank < self.world - 1
+        self.g_lo = self.G if self.has_lo else 0
+        self.g_hi = self.G if self.has_hi else 0
+        self.x_off = self.o0 - self.g_lo            # global row of local row 0
+        self.nxl = (self.o1 - self.o0) + self.g_lo + self.g_hi
+        if self.o1 - self.o0 < self.G:
+            raise ValueError(f"slab of {self.o1 - self.o0} rows is thinner than the ghost width {self.G}")
+
+    def update_range(self, j):
+        """Local rows [r0, r1) that step j (1-based) of a cycle may update."""
+        r0 = self.h * j if self.has_lo else 0
+        r1 = self.nxl - (self.h * j if self.has_hi else 0)
+        return r0, r1
+
+    # local row ranges of the halo blocks
+    def send_lo(self):  # my first G owned rows -> left neighbour's right ghost
+        return self.g_lo, self.g_lo + self.G
+
+    def send_hi(self):  # my last G owned rows -> right neighbour's left ghost
+        return self.nxl - self.g_hi - self.G, self.nxl - self.g_hi
+
+    def recv_lo(self):
+        return 0, self.g_lo
+
+    def recv_hi(self):
+        return self.nxl - self.g_hi, self.nxl
+
+
+class HipSlabStepper:
+    """Product stepper: one FDWave slab context, fused forward step on the given rows."""
+
+    def __init__(self, fdwave_ctx):
+        self.ctx = fdwave_ctx
+
+    def step(self, d_p, d_pp, d_v2, r0, r1, it, first, d_srce, sx, sz, stream):
+        from ._lib import MODE_FWD
+        inj = d_srce.data_ptr() + 4 * it if d_srce is not None else None
+        self.ctx.dev_step(MODE_FWD, d_p.data_ptr(), d_pp.data_ptr(), d_v2.data_ptr(), r0, r1, pp_twice=not first,
+                          d_inj=inj, inj_x=sx if d_srce is not None else -1, inj_z=sz, stream=stream)
+
+
+class SlabForward:
+    """fd_forward's loop (fd-code.cu:259-267) on one slab of a decomposed grid."""
+
+    def __init__(self, geom, stepper, fields, v2, srce=None, sx=-1, sz=0, group=None, overlap=True):
+        self.g, self.stepper = geom, stepper
+        self.a, self.b = fields            # two [nxl][pitch] tensors: roles swap every step
+        self.v2, self.srce, self.sx, self.sz = v2, srce, sx, sz
+        self.group = group
+        self.cuda = self.a.is_cuda
+        self.overlap = overlap
+        self.it = 0
+        self.d_p, self.d_pp = self.a, self.b
+        self._ops = None
+        self.fresh = False          # ghosts of both fields are up to date
+        if geom.world > 1 and (geom.o1 - geom.o0) < 2 * geom.G:
+            self.overlap = False    # strips would collide: fall back to exchange-then-compute
+        if self.cuda:
+            self.compute = torch.cuda.Stream()
+            self.comm = torch.cuda.Stream()
+
+    # ---- halo exchange ------------------------------------------------------------------------
+    def _exchange_ops(self):
+        """P2P descriptors for both time levels, built once (the views alias fixed memory)."""
+        if self._ops is None:
+            g, ops = self.g, []
+            for f in (self.a, self.b):
+                if g.has_lo:
+                    s0, s1 = g.send_lo()
+                    r0, r1 = g.recv_lo()
+                    ops.append(dist.P2POp(dist.isend, f[s0:s1], g.rank - 1, group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, f[r0:r1], g.rank - 1, group=self.group))
+                if g.has_hi:
+                    s0, s1 = g.send_hi()
+                    r0, r1 = g.recv_hi()
+                    ops.append(dist.P2POp(dist.isend, f[s0:s1], g.rank + 1, group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, f[r0:r1], g.rank + 1, group=self.group))
+            self._ops = ops
+        return self._ops
+
+    def exchange(self, wait_compute=True):
+        """Refresh the ghost rows of both fields.  On GPU the transfer runs on the comm stream: it
+        starts after everything already queued on the compute stream (or after `self._halo_ready`
+        when the caller recorded one) and the compute stream is NOT made to wait here."""
+        ops = self._exchange_ops()
+        if not ops:
+            return
+        if self.cuda:
+            if wait_compute:
+                self.comm.wait_stream(self.compute)
+            with torch.cuda.stream(self.comm):
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+        else:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        self.fresh = True
+
+    # ---- time loop ----------------------------------------------------------------------------
+    def _step(self, r0, r1, stream):
+        if r1 > r0:
+            self.stepper.step(self.d_p, self.d_pp, self.v2, r0, r1, self.it, self.it == 0, self.srce, self.sx, self.sz, stream)
+
+    def run(self, nsteps):
+        """nsteps forward iterations.  Cycle = exchange, then ksteps steps on shrinking row ranges.
+        With overlap the exchange that opens the NEXT cycle is started as soon as the two boundary
+        strips of the cycle's last step exist, and runs beside that step's interior rows."""
+        g = self.g
+        stream = self.compute.cuda_stream if self.cuda else None
+        done = 0
+        while done < nsteps:
+            kk = min(g.ksteps, nsteps - done)
+            if g.world > 1 and not self.fresh:
+                self.exchange()
+            if self.cuda and g.world > 1:
+                self.compute.wait_stream(self.comm)        # ghosts must have landed before they are read
+            self.fresh = False
+            for j in range(1, kk + 1):
+                self.d_p, self.d_pp = self.d_pp, self.d_p      # fd-code.cu:260-262
+                r0, r1 = g.update_range(j)
+                last_full = self.overlap and g.world > 1 and j == g.ksteps and done + kk < nsteps
+                if last_full:
+                    # r0 == g_lo and r1 == nxl - g_hi here: the strips are the rows the neighbours need
+                    lo_end = r0 + g.G if g.has_lo else r0
+                    hi_beg = r1 - g.G if g.has_hi else r1
+                    self._step(r0, lo_end, stream)
+                    self._step(hi_beg, r1, stream)
+                    self.exchange()                             # comm stream: waits for the strips only
+                    self._step(lo_end, hi_beg, stream)          # interior, concurrent with the transfer
+                else:
+                    self._step(r0, r1, stream)
+                self.it += 1
+            done += kk
+        return self.d_p, self.d_pp
+
+    def synchronize(self):
+        if self.cuda:
+            self.compute.synchronize()
+            self.comm.synchronize()
+
+    def owned(self, f):
+        """The owned rows of a local field (drops ghosts)."""
+        return f[self.g.g_lo:self.g.nxl - self.g.g_hi]

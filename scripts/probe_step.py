@@ -35,7 +35,9 @@ def run(n, xchunk, wz, pf=0, steps=200, warm=20, mode="fwd"):
 if __name__ == "__main__":
     sizes = [int(a) for a in sys.argv[1:]] or [4096, 8192]
     for n in sizes:
-        for pf in (2, 3):
-            for xchunk in (0, 16, 32, 43, 64, 128):
+        for pf in (2, 3, 1):
+            for xchunk in (8, 10, 12, 16, 20, 24, 32, 48, 64, 96, 128):
+                if pf != 2 and xchunk not in (12, 24, 64):
+                    continue
                 ms, g = run(n, xchunk, 4, pf)
                 print(f"n={n} pf={pf} xchunk={xchunk:3d}: {ms*1e3:8.1f} us/step  {g:7.1f} Gpt/s  {g*16/1e3:6.2f} TB/s algorithmic ({g*16/8000*100:5.1f}% of 8 TB/s)", flush=True)
