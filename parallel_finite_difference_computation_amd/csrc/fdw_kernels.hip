@@ -86,17 +86,32 @@ __device__ __forceinline__ f4 f4_zero()
     r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.0f;
     return r;
 }
+// Cache policy of the streams (FDW_NT bitmask; measured in scripts/ubench/rwmix.hip and on the kernel):
+//   1 pointwise inputs (pp, v2, psrc, img) are read once per step -> nontemporal loads
+//   2 the result is not read again in this launch               -> nontemporal store
+//   4 p rows (re-read by the neighbouring chunk as halo)        -> default policy unless set
+#ifndef FDW_NT
+#define FDW_NT 3
+#endif
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 // scalar (wave-uniform) row base + 32-bit per-lane byte offset: global_load saddr + voffset form
-__device__ __forceinline__ f4 f4_load(const float* row, unsigned voff_bytes)
+template <bool NT>
+__device__ __forceinline__ f4 f4_load_t(const float* row, unsigned voff_bytes)
 {
-    const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(row) + voff_bytes);
+    const v4f* ptr = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(row) + voff_bytes);
+    const v4f t = NT ? __builtin_nontemporal_load(ptr) : *ptr;
     f4 r;
     r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
     return r;
 }
+__device__ __forceinline__ f4 f4_load(const float* row, unsigned voff_bytes) { return f4_load_t<(FDW_NT & 4) != 0>(row, voff_bytes); }
+__device__ __forceinline__ f4 f4_load_stream(const float* row, unsigned voff_bytes) { return f4_load_t<(FDW_NT & 1) != 0>(row, voff_bytes); }
 __device__ __forceinline__ void f4_store(float* row, unsigned voff_bytes, const f4& a)
 {
-    *reinterpret_cast<float4*>(reinterpret_cast<char*>(row) + voff_bytes) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    v4f* ptr = reinterpret_cast<v4f*>(reinterpret_cast<char*>(row) + voff_bytes);
+    const v4f t = {a.v[0], a.v[1], a.v[2], a.v[3]};
+    if (FDW_NT & 2) __builtin_nontemporal_store(t, ptr); else *ptr = t;
 }
 
 template <int N, class F>
@@ -255,7 +270,7 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
 #endif
         return f4_load(a.p + (size_t)row * pitch, hoff);
     };
-    auto load_plain = [&](const float* base, int row) -> f4 { return f4_load(base + (size_t)row * pitch, voff); };
+    auto load_plain = [&](const float* base, int row) -> f4 { return f4_load_stream(base + (size_t)row * pitch, voff); };
 
     // ---- prologue: ring rows xa-H .. xa-H+R-1; pointwise rows xa .. xa+PF-1 --------------------
     // Issue order matters: the loop-header s_waitcnt is the stricter of (prologue state, end-of-turn
