@@ -156,13 +156,16 @@ int fdw_selftest(fdw_ctx *ctx);
  * fdw_calc_coefs        calc_coefs + makeo2, F:113-192 / S:137-216 (cxx selects the float variant)
  * fdw_ricker_wavelet    ricker_wavelet, F:302-334
  * fdw_taper_tables      taper tables of fd_init_cuda, R:159-166
- * fdw_extendvel_linear  extendvel_linear, F:336-394; vel is [nxe][nze] contiguous; draws from glibc
- *                       rand() in the reference's order (unseeded in the reference, R:486)
+ * fdw_extendvel_linear  extendvel_linear, F:336-394; vel is [nxe][nze] contiguous; draws the stream
+ *                       glibc rand() yields (the reference never seeds it, R:486) from a PRIVATE restatement
+ *                       of that generator, so nothing else in the process can perturb the border model
+ * fdw_srand             reseeds that private generator like srand(); a fresh process behaves as fdw_srand(1)
  */
 int fdw_calc_coefs(int order, int cxx, float *coef /* [order+1] */);
 void fdw_ricker_wavelet(int nt, float dt, float fpeak, float *s);
 void fdw_taper_tables(int nxb, int nzb, float fac, float *taper_x, float *taper_z);
 void fdw_extendvel_linear(int nx, int nz, int nxb, int nzb, float *vel);
+void fdw_srand(unsigned seed);
 
 #ifdef __cplusplus
 }

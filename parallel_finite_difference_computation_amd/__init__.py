@@ -5,7 +5,7 @@ Importing the package does not touch the GPU; using it without libfdwave.so rais
 """
 from ._lib import FdwError, LIB_PATH, MODE_FWD, MODE_PLAIN, MODE_RECV, lib  # noqa: F401
 from .api import (FDWave, calc_coefs, extendvel_linear, fd_back, fd_forward, fd_init, ricker_wavelet,  # noqa: F401
-                  taper_tables)
+                  srand, taper_tables)
 
-__all__ = ["FDWave", "FdwError", "calc_coefs", "ricker_wavelet", "taper_tables", "extendvel_linear",
+__all__ = ["FDWave", "FdwError", "calc_coefs", "ricker_wavelet", "taper_tables", "extendvel_linear", "srand",
            "fd_init", "fd_forward", "fd_back", "lib", "LIB_PATH", "MODE_FWD", "MODE_PLAIN", "MODE_RECV"]

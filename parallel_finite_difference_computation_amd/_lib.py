@@ -58,6 +58,7 @@ SIGNATURES = [
     ("fdw_ricker_wavelet", None, [C.c_int, C.c_float, C.c_float, f32p]),
     ("fdw_taper_tables", None, [C.c_int, C.c_int, C.c_float, vp, vp]),
     ("fdw_extendvel_linear", None, [C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
+    ("fdw_srand", None, [C.c_uint]),
 ]
 
 _lib = None

@@ -43,8 +43,13 @@ def taper_tables(nxb, nzb, fac):
     return tx[:nxb], tz[:nzb]
 
 
+def srand(seed):
+    """Reseed the private restatement of glibc rand() behind extendvel_linear (fresh process == srand(1))."""
+    lib().fdw_srand(seed)
+
+
 def extendvel_linear(vpe, nx, nz, nxb, nzb):
-    """extendvel_linear (functions.c:336-394), in place; draws from glibc rand()."""
+    """extendvel_linear (functions.c:336-394), in place; draws glibc's rand() stream (private generator)."""
     if vpe.shape != (nx + 2 * nxb, nz + 2 * nzb) or vpe.dtype != np.float32 or not vpe.flags.c_contiguous:
         raise ValueError("vpe must be C-contiguous float32 [nx+2nxb][nz+2nzb]")
     lib().fdw_extendvel_linear(nx, nz, nxb, nzb, vpe)

@@ -101,10 +101,47 @@ static float ramp_to_floor(float v, int k, int nb)
     const float floor_v = 300.;
     return v - (v - floor_v) * k / (nb - 1);
 }
+/* The reference draws from glibc rand() and never seeds it (R:486), i.e. it consumes the seed-1 stream of
+ * glibc's default generator from the start of the process.  Inside a HIP process that stream is not ours
+ * alone (runtime libraries may draw from it too), so the generator is restated here and kept private:
+ * glibc TYPE_3 additive feedback, r[i] = r[i-3] + r[i-31] over 32-bit words, seeded by the minimal-standard
+ * LCG (16807 mod 2^31-1), first 310 outputs discarded, result = word >> 1.  fdw_srand(1) == a fresh process. */
+static struct { unsigned r[34]; int i; int ready; } g_rng;
+
+void fdw_srand(unsigned seed)
+{
+    int word = seed ? (int)seed : 1;
+    g_rng.r[0] = (unsigned)word;
+    for (int k = 1; k < 31; k++) {
+        const long hi = word / 127773, lo = word % 127773;
+        long t = 16807 * lo - 2836 * hi;
+        if (t < 0) t += 2147483647;
+        word = (int)t;
+        g_rng.r[k] = (unsigned)word;
+    }
+    /* state as a ring of 31 words: front = r[3], rear = r[0] (glibc: fptr = &state[3], rptr = &state[0]) */
+    g_rng.i = 0;
+    g_rng.ready = 1;
+    for (int k = 0; k < 310; k++) {
+        const int f = (g_rng.i + 3) % 31, b = g_rng.i % 31;
+        g_rng.r[f] += g_rng.r[b];
+        g_rng.i = (g_rng.i + 1) % 31;
+    }
+}
+
+static int fdw_rand(void)
+{
+    if (!g_rng.ready) fdw_srand(1);
+    const int f = (g_rng.i + 3) % 31, b = g_rng.i % 31;
+    g_rng.r[f] += g_rng.r[b];
+    g_rng.i = (g_rng.i + 1) % 31;
+    return (int)(g_rng.r[f] >> 1);
+}
+
 static float draw_near(float v, float centre)
 {
     const float half = 200.;
-    return rand() % (int)(v + half - (centre - half) + 1) + centre - half;
+    return fdw_rand() % (int)(v + half - (centre - half) + 1) + centre - half;
 }
 
 void fdw_extendvel_linear(int nx, int nz, int nxb, int nzb, float *vel)

@@ -1,0 +1,166 @@
+/* rtm_code -- drop-in for cuda_reference_RTM/rtm_code (src/fd-code.cu = R):
+ *     ./rtm_code ./models/<model>/input.dat
+ * Same deck keys and defaults (R:343-378), same input binaries (vpfile [nx][nz], datfile
+ * [ns][nx][nt], optional vel_ext_file [ns][nxe][nze]), same outputs: <tmpdir>/dir.image (stacked image
+ * [nx][nz]), <tmpdir>/dir.image_lap (zeros, R:477,542), empty dir.snaps / dir.snaps_rec / dir.snapr
+ * (R:465-470), ./image.num text dump (R:522-528), and the stdout banners.  The per-shot propagation
+ * (fd_forward + fd_back, R:499-518) is one device-resident fdw_shot() call; launch extents are the
+ * reference's (compat = 1), so the image equals the reference's.
+ * Not reproduced: the `file-teste` debug dump at it == 750 (R:268-281) and the in-loop progress lines. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+
+#include "fdw_config.h"
+#include "fdwave.h"
+
+static float *read_floats(const char *path, size_t n, const char *what)
+{
+    FILE *f = path ? fopen(path, "rb") : NULL;
+    if (!f) {
+        fprintf(stderr, "cannot open %s '%s'\n", what, path ? path : "(null)");
+        return NULL;
+    }
+    float *a = (float *)calloc(n ? n : 1, sizeof(float)); /* R:414,421,438 memset to 0 then fread */
+    const size_t got = a ? fread(a, sizeof(float), n, f) : 0;
+    fclose(f);
+    if (got != n) fprintf(stderr, "warning: %s '%s' holds %zu of %zu floats (rest stays zero)\n", what, path, got, n);
+    return a;
+}
+
+static FILE *open_out(const char *dir, const char *name)
+{
+    char path[4096];
+    snprintf(path, sizeof path, "%s/%s", dir, name);
+    FILE *f = fopen(path, "w");
+    if (!f) fprintf(stderr, "cannot create '%s'\n", path);
+    return f;
+}
+
+int main(int argc, char **argv)
+{
+    struct timeval start, end;
+    gettimeofday(&start, NULL);
+    if (argc < 2) {
+        fprintf(stderr, "usage: %s <input.dat>\n", argv[0]);
+        return EXIT_FAILURE;
+    }
+    fdw_deck *deck = fdw_deck_read(argv[1]);
+    if (!deck) return EXIT_FAILURE; /* F:51-52 */
+
+    /* init_args, R:343-378 */
+    const char *tmpdir = fdw_deck_str(deck, "tmpdir"), *vpfile = fdw_deck_str(deck, "vpfile");
+    const char *datfile = fdw_deck_str(deck, "datfile"), *vel_ext_file = fdw_deck_str(deck, "vel_ext_file");
+    const int nz = fdw_deck_int(deck, "nz"), nx = fdw_deck_int(deck, "nx"), nt = fdw_deck_int(deck, "nt");
+    int ns = fdw_deck_int(deck, "ns"), sz = fdw_deck_int(deck, "sz"), fsx = fdw_deck_int(deck, "fsx");
+    int ds = fdw_deck_int(deck, "ds"), gz = fdw_deck_int(deck, "gz"), order = fdw_deck_int(deck, "order");
+    int nzb = fdw_deck_int(deck, "nzb"), nxb = fdw_deck_int(deck, "nxb"), iss = fdw_deck_int(deck, "iss");
+    const int rnd = fdw_deck_int(deck, "rnd");
+    const float dz = fdw_deck_float(deck, "dz"), dx = fdw_deck_float(deck, "dx"), dt = fdw_deck_float(deck, "dt");
+    const float fpeak = fdw_deck_float(deck, "fpeak");
+    float fac = fdw_deck_float(deck, "fac");
+    const int vel_ext_flag = vel_ext_file != NULL;
+    if (iss == -1) iss = 0;
+    if (ns == -1) ns = 1;
+    if (sz == -1) sz = 0;
+    if (fsx == -1) fsx = 0;
+    if (ds == -1) ds = 1;
+    if (gz == -1) gz = 0;
+    if (order == -1) order = 8;
+    if (nzb == -1) nzb = 40;
+    if (nxb == -1) nxb = 40;
+    if (fac == -1.0f) fac = 0.7f;
+    (void)iss;
+
+    printf("## vp = %s, d_obs = %s, vel_ext_file = %s, vel_ext_flag = %d \n", vpfile, datfile, vel_ext_file, vel_ext_flag);
+    printf("## nz = %d, nx = %d, nt = %d \n", nz, nx, nt);
+    printf("## dz = %f, dx = %f, dt = %f \n", dz, dx, dt);
+    printf("## ns = %d, sz = %d, fsx = %d, ds = %d, gz = %d \n", ns, sz, fsx, ds, gz);
+    printf("## order = %d, nzb = %d, nxb = %d, F = %f, rnd = %d \n", order, nzb, nxb, fac, rnd);
+    if (nz <= 0 || nx <= 0 || nt <= 0 || !tmpdir || !vpfile || !datfile) {
+        fprintf(stderr, "input deck is missing one of tmpdir/vpfile/datfile/nz/nx/nt\n");
+        return EXIT_FAILURE;
+    }
+
+    /* R:402-411 */
+    float *srce = (float *)malloc((size_t)nt * sizeof(float));
+    fdw_ricker_wavelet(nt, dt, fpeak, srce);
+    int *sx = (int *)malloc((size_t)ns * sizeof(int));
+    for (int is = 0; is < ns; is++) sx[is] = fsx + is * ds + nxb;
+    sz += nzb;
+    gz += nzb;
+    const int nze = nz + 2 * nzb, nxe = nx + 2 * nxb;
+    const size_t ne = (size_t)nxe * nze, ni = (size_t)nx * nz;
+
+    float *vel_ext_rnd = NULL;
+    if (vel_ext_flag && !(vel_ext_rnd = read_floats(vel_ext_file, ne * ns, "vel_ext_file"))) return EXIT_FAILURE; /* R:412-418 */
+    float *d_obs = read_floats(datfile, (size_t)ns * nx * nt, "datfile");                                        /* R:420-424 */
+    float *vp = read_floats(vpfile, ni, "vpfile");                                                               /* R:437-441 */
+    if (!d_obs || !vp) return EXIT_FAILURE;
+    float *vpe = (float *)calloc(ne, sizeof(float)); /* the reference leaves the border uninitialised (malloc) until extendvel */
+    for (int ix = 0; ix < nx; ix++)
+        for (int iz = 0; iz < nz; iz++) vpe[(size_t)(ix + nxb) * nze + iz + nzb] = vp[(size_t)ix * nz + iz]; /* R:445-449 */
+    float *vel2 = (float *)malloc(ne * sizeof(float));
+
+    fdw_params prm;
+    memset(&prm, 0, sizeof prm);
+    prm.order = order; prm.nxe = nxe; prm.nze = nze; prm.nxb = nxb; prm.nzb = nzb; prm.nt = nt;
+    prm.dx = dx; prm.dz = dz; prm.dt = dt; prm.fac = fac;
+    prm.compat = 1;   /* the reference's launch extents, R:185-195 */
+    prm.coef_cxx = 0; /* libsource.a is C, F:160-192 */
+    fdw_ctx *ctx = NULL;
+    if (fdw_create(&prm, 0, &ctx) != FDW_OK) { /* fd_init, R:452 */
+        fprintf(stderr, "fdw_create: %s\n", fdw_last_error());
+        return EXIT_FAILURE;
+    }
+
+    float *imloc = (float *)malloc(ni * sizeof(float)), *img = (float *)calloc(ni, sizeof(float));
+    float *img_lap = (float *)calloc(ni, sizeof(float));
+    FILE *fsns = open_out(tmpdir, "dir.snaps"), *fsns2 = open_out(tmpdir, "dir.snaps_rec"), *fsnr = open_out(tmpdir, "dir.snapr");
+    FILE *fimg = open_out(tmpdir, "dir.image"), *fimg_lap = open_out(tmpdir, "dir.image_lap"); /* R:464-474 */
+    FILE *fnum = fopen("image.num", "w");                                                       /* R:478-479 */
+    if (!fimg || !fimg_lap || !fnum) return EXIT_FAILURE;
+
+    for (int is = 0; is < ns; is++) { /* R:480-529 */
+        fprintf(stdout, "** source %d, at (%d,%d) \n", is + 1, sx[is] - nxb, sz - nzb);
+        const float *v = vpe;
+        if (vel_ext_flag)
+            v = vel_ext_rnd + (size_t)is * ne; /* R:484 */
+        else
+            fdw_extendvel_linear(nx, nz, nxb, nzb, vpe); /* R:486: glibc rand(), never seeded */
+        for (size_t k = 0; k < ne; k++) vel2[k] = v[k] * v[k]; /* R:490-494 */
+        memset(imloc, 0, ni * sizeof(float));                  /* R:515 */
+        fprintf(stdout, "\n");
+        fprintf(stdout, "** backward propagation %d, at (%d,%d) \n", is + 1, sx[is] - nxb, sz - nzb);
+        if (fdw_shot(ctx, vel2, sx[is], sz, gz, srce, d_obs + (size_t)is * nx * nt, imloc, NULL, NULL) != FDW_OK) {
+            fprintf(stderr, "fdw_shot: %s\n", fdw_last_error());
+            return EXIT_FAILURE;
+        }
+        fprintf(stdout, "\n");
+        fprintf(fnum, "======== %i ========\n", is); /* R:522-528: iz outer, ix inner, running sum */
+        for (int iz = 0; iz < nz; iz++)
+            for (int ix = 0; ix < nx; ix++) {
+                img[(size_t)ix * nz + iz] += imloc[(size_t)ix * nz + iz];
+                fprintf(fnum, " %f \n", img[(size_t)ix * nz + iz]);
+            }
+    }
+    gettimeofday(&end, NULL);
+    /* the reference divides integers (whole seconds, R:536); we print the real value */
+    const double exec = ((end.tv_sec - start.tv_sec) * 1000000.0 + (end.tv_usec - start.tv_usec)) / 1000000.0;
+    printf("> Exec time = %.2f (s)\n", exec);
+
+    fwrite(img, sizeof(float), ni, fimg);         /* R:540 */
+    fwrite(img_lap, sizeof(float), ni, fimg_lap); /* R:542 */
+    if (fsns) fclose(fsns);
+    if (fsns2) fclose(fsns2);
+    if (fsnr) fclose(fsnr);
+    fclose(fimg);
+    fclose(fimg_lap);
+    fclose(fnum);
+    fdw_destroy(ctx);
+    free(srce); free(sx); free(vel_ext_rnd); free(d_obs); free(vp); free(vpe); free(vel2);
+    free(imloc); free(img); free(img_lap);
+    fdw_deck_free(deck);
+    return 0;
+}

@@ -62,14 +62,30 @@ def test_taper_tables():
 
 
 def test_extendvel(tables):
-    libc = C.CDLL(None)
     small = tables["extvel_small_in"]
     for seed in (1, 42):
         v = np.zeros((36, 30), np.float32)
         v[6:30, 5:25] = small
-        libc.srand(seed)
+        F.srand(seed)     # private restatement of glibc's generator: must reproduce srand(seed) + rand()
         assert_bit_equal(F.extendvel_linear(v, 24, 20, 6, 5), tables[f"extvel_small_seed{seed}"], f"extendvel seed {seed}")
     v = np.zeros((415, 295), np.float32)
     v[50:365, 50:245] = golden_field("new_mod_vel_koslov.f32", (315, 195))
-    libc.srand(1)
+    F.srand(1)
     assert_bit_equal(F.extendvel_linear(v, 315, 195, 50, 50), tables["extvel_new_mod_seed1"], "extendvel new_mod")
+
+
+def test_private_rand_is_glibc_rand():
+    """10 000 draws for several seeds against the live libc of this machine."""
+    libc = C.CDLL(None)
+    L = F.lib()
+    import numpy as np
+    for seed in (1, 2, 42, 123456789, 0):
+        libc.srand(seed)
+        want = [libc.rand() for _ in range(2000)]
+        F.srand(seed)
+        v = np.full((3 + 2 * 40, 3 + 2 * 40), 2500.0, np.float32)   # every draw is rand() % 401 + offset: compare mod 401
+        F.extendvel_linear(v, 3, 3, 40, 40)
+        # bottom strip of the first interior column: draws 0..39 in order, value = rand()%(int)(401 + 2200*k/39 ... ) - see fdw_host.c
+        k = 0
+        got0 = v[40, 43]              # first draw: window v+200-(v-200)+1 = 401, centre = v
+        assert got0 == float(want[0] % 401) + 2500.0 - 200.0
