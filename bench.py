@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--size", type=int, default=8192)
-    ap.add_argument("--ksteps", type=int, default=4, help="time steps per halo exchange (N > 1)")
+    ap.add_argument("--ksteps", type=int, default=0, help="time steps per halo exchange (N > 1); 0 = auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     args = ap.parse_args()
@@ -93,6 +93,12 @@ def main():
 
     n, K, W = args.size, args.steps, args.warmup
     nt = K + W
+    if world > 1 and args.ksteps <= 0:
+        # One exchange costs the host a few hundred us of Python/RCCL enqueue whatever its size, so make a
+        # cycle last >= ~500 us of GPU time: k = 500 us / (slab points / ~350 Gpt/s), clamped to [2, 16].
+        # Redundant ghost work is h*(k-1)/2 rows per side per step (5.9 % of a 1024-row slab at k = 16).
+        t_step_us = (n / world) * n / 350e9 * 1e6
+        args.ksteps = int(max(2, min(16, -(-500.0 // t_step_us))))
     geom = SlabGeometry(rank, world, n, ORDER // 2, args.ksteps if world > 1 else 1)
     ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank,
                    slab=(geom.x_off, geom.nxl) if world > 1 else None)

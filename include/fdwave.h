@@ -118,6 +118,9 @@ int fdw_shot(fdw_ctx *ctx, const float *v2, int sx, int sz, int gz, const float 
  * fdw_dev_taper_finalize  applies the one taper pass the lazy scheme still owes to a field that was
  *                 last used as d_p (needed before it is exported or used untapered).
  * fdw_dev_laplacian  mode 3: d_lap = Laplacian(d_p), zero outside the interior.
+ * fdw_dev_steps_shrink  like fdw_dev_steps for one slab of a decomposed grid between two halo exchanges:
+ *                 step j = j0.. of the cycle updates rows [h*j, nxl - h*j) on the sides that have a
+ *                 neighbour (shrink_lo / shrink_hi), see decomp.py.
  * fdw_dev_steps   nsteps FWD steps with internal role swapping; *d_srce is srce[] on the device
  *                 (may be NULL = no source).  After an odd number of steps the newest field is in
  *                 the buffer passed as d_pp, after an even number in d_p (as in the reference loop).
@@ -129,6 +132,8 @@ int fdw_dev_step(fdw_ctx *ctx, int mode, const float *d_p, float *d_pp, const fl
                  void *stream);
 int fdw_dev_steps(fdw_ctx *ctx, float *d_p, float *d_pp, const float *d_v2, const float *d_srce, int sx, int sz,
                   int it0, int nsteps, int first_pp_twice, void *stream);
+int fdw_dev_steps_shrink(fdw_ctx *ctx, float *d_p, float *d_pp, const float *d_v2, const float *d_srce, int sx, int sz,
+                         int it0, int nsteps, int first_pp_twice, int j0, int shrink_lo, int shrink_hi, void *stream);
 int fdw_dev_taper_finalize(fdw_ctx *ctx, float *d_f, void *stream);
 int fdw_dev_laplacian(fdw_ctx *ctx, const float *d_p, float *d_lap, void *stream);
 

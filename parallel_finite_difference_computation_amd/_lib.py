@@ -46,6 +46,7 @@ SIGNATURES = [
     ("fdw_field_bytes", C.c_size_t, [vp]),
     ("fdw_dev_step", C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),
     ("fdw_dev_steps", C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    ("fdw_dev_steps_shrink", C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 8 + [vp]),
     ("fdw_dev_taper_finalize", C.c_int, [vp, vp, vp]),
     ("fdw_dev_laplacian", C.c_int, [vp, vp, vp, vp]),
     ("fdw_upload_field", C.c_int, [vp, vp, f32p]),

@@ -156,6 +156,10 @@ class FDWave:
     def dev_steps(self, d_p, d_pp, d_v2, d_srce, sx, sz, it0, nsteps, first_pp_twice=False, stream=None):
         check(lib().fdw_dev_steps(self._h, d_p, d_pp, d_v2, d_srce, sx, sz, it0, nsteps, int(first_pp_twice), stream))
 
+    def dev_steps_shrink(self, d_p, d_pp, d_v2, d_srce, sx, sz, it0, nsteps, first_pp_twice, j0, shrink_lo, shrink_hi, stream=None):
+        check(lib().fdw_dev_steps_shrink(self._h, d_p, d_pp, d_v2, d_srce, sx, sz, it0, nsteps, int(first_pp_twice), j0,
+                                         int(shrink_lo), int(shrink_hi), stream))
+
     def dev_taper_finalize(self, d_f, stream=None):
         check(lib().fdw_dev_taper_finalize(self._h, d_f, stream))
 

@@ -391,6 +391,26 @@ extern "C" int fdw_dev_steps(fdw_ctx* c, float* d_p, float* d_pp, const float* d
     return FDW_OK;
 }
 
+// ksteps-cycle of the slab decomposition in one call: step j (1-based, j = j0 .. j0+nsteps-1) updates the
+// rows still valid on the interior sides, [h*j, nxl - h*j) (decomp.py "deep halos").
+extern "C" int fdw_dev_steps_shrink(fdw_ctx* c, float* d_p, float* d_pp, const float* d_v2, const float* d_srce, int sx, int sz,
+                                    int it0, int nsteps, int first_pp_twice, int j0, int shrink_lo, int shrink_hi, void* stream)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    hipStream_t s = pick_stream(c, stream);
+    for (int k = 0; k < nsteps; k++) {
+        std::swap(d_p, d_pp);  // R:260-262
+        const int j = j0 + k;
+        const int r0 = shrink_lo ? c->h * j : 0;
+        const int r1 = c->nxl - (shrink_hi ? c->h * j : 0);
+        if (r1 <= r0) return fail(FDW_EINVAL, "steps_shrink: slab exhausted at cycle step %d", j);
+        int rc = step_impl(c, FDW_MODE_FWD, d_p, d_pp, d_v2, r0, r1, (k > 0) || first_pp_twice, d_srce ? d_srce + it0 + k : nullptr,
+                           d_srce ? sx : -1, sz, nullptr, nullptr, s);
+        if (rc) return rc;
+    }
+    return FDW_OK;
+}
+
 extern "C" int fdw_dev_taper_finalize(fdw_ctx* c, float* d_f, void* stream)
 {
     if (!c || !d_f) return fail(FDW_EINVAL, "ctx or field is NULL");

@@ -86,6 +86,12 @@ class HipSlabStepper:
                           d_inj=inj, inj_x=sx if d_srce is not None else -1, inj_z=sz, stream=stream)
 
 
+    def steps_shrink(self, d_p, d_pp, d_v2, it0, nsteps, first, d_srce, sx, sz, j0, shrink_lo, shrink_hi, stream):
+        """nsteps consecutive cycle steps j0.. in ONE library call (role swaps and shrinking ranges in C)."""
+        self.ctx.dev_steps_shrink(d_p.data_ptr(), d_pp.data_ptr(), d_v2.data_ptr(), d_srce.data_ptr() if d_srce is not None else None,
+                                  sx, sz, it0, nsteps, not first, j0, shrink_lo, shrink_hi, stream=stream)
+
+
 class SlabForward:
     """fd_forward's loop (fd-code.cu:259-267) on one slab of a decomposed grid."""
 
@@ -148,6 +154,38 @@ class SlabForward:
         if r1 > r0:
             self.stepper.step(self.d_p, self.d_pp, self.v2, r0, r1, self.it, self.it == 0, self.srce, self.sx, self.sz, stream)
 
+    def cycle(self, kk, more_after, stream):
+        """One cycle as a generator: yields "pre" where the ghosts must be valid (cycle start) and "mid"
+        where the NEXT cycle's exchange can start (overlap).  `run` drives it with RCCL; tests drive several
+        slabs in lockstep on one GPU with in-process copies at the yields."""
+        g = self.g
+        yield "pre"
+        split_last = self.overlap and g.world > 1 and kk == g.ksteps and more_after
+        nbulk = kk - 1 if split_last else kk
+        j_next = 1
+        if nbulk > 0 and hasattr(self.stepper, "steps_shrink"):
+            # the plain steps of the cycle in one library call (keeps the host ahead of the GPU)
+            self.stepper.steps_shrink(self.d_p, self.d_pp, self.v2, self.it, nbulk, self.it == 0, self.srce, self.sx, self.sz,
+                                      1, g.has_lo, g.has_hi, stream)
+            if nbulk % 2:
+                self.d_p, self.d_pp = self.d_pp, self.d_p
+            self.it += nbulk
+            j_next = nbulk + 1
+        for j in range(j_next, kk + 1):
+            self.d_p, self.d_pp = self.d_pp, self.d_p      # fd-code.cu:260-262
+            r0, r1 = g.update_range(j)
+            if split_last and j == kk:
+                # r0 == g_lo and r1 == nxl - g_hi here: the strips are the rows the neighbours need
+                lo_end = r0 + g.G if g.has_lo else r0
+                hi_beg = r1 - g.G if g.has_hi else r1
+                self._step(r0, lo_end, stream)
+                self._step(hi_beg, r1, stream)
+                yield "mid"                                 # exchange on the comm stream: waits for the strips only
+                self._step(lo_end, hi_beg, stream)          # interior, concurrent with the transfer
+            else:
+                self._step(r0, r1, stream)
+            self.it += 1
+
     def run(self, nsteps):
         """nsteps forward iterations.  Cycle = exchange, then ksteps steps on shrinking row ranges.
         With overlap the exchange that opens the NEXT cycle is started as soon as the two boundary
@@ -157,26 +195,17 @@ class SlabForward:
         done = 0
         while done < nsteps:
             kk = min(g.ksteps, nsteps - done)
-            if g.world > 1 and not self.fresh:
-                self.exchange()
-            if self.cuda and g.world > 1:
-                self.compute.wait_stream(self.comm)        # ghosts must have landed before they are read
-            self.fresh = False
-            for j in range(1, kk + 1):
-                self.d_p, self.d_pp = self.d_pp, self.d_p      # fd-code.cu:260-262
-                r0, r1 = g.update_range(j)
-                last_full = self.overlap and g.world > 1 and j == g.ksteps and done + kk < nsteps
-                if last_full:
-                    # r0 == g_lo and r1 == nxl - g_hi here: the strips are the rows the neighbours need
-                    lo_end = r0 + g.G if g.has_lo else r0
-                    hi_beg = r1 - g.G if g.has_hi else r1
-                    self._step(r0, lo_end, stream)
-                    self._step(hi_beg, r1, stream)
-                    self.exchange()                             # comm stream: waits for the strips only
-                    self._step(lo_end, hi_beg, stream)          # interior, concurrent with the transfer
+            for tag in self.cycle(kk, done + kk < nsteps, stream):
+                if g.world == 1:
+                    continue
+                if tag == "pre":
+                    if not self.fresh:
+                        self.exchange()
+                    if self.cuda:
+                        self.compute.wait_stream(self.comm)    # ghosts must have landed before they are read
+                    self.fresh = False
                 else:
-                    self._step(r0, r1, stream)
-                self.it += 1
+                    self.exchange()
             done += kk
         return self.d_p, self.d_pp
 

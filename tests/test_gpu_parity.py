@@ -295,3 +295,66 @@ def test_slab_contexts_match_single_domain_on_one_gpu(world, ksteps, compat):
     own = lambda R, f: R[f][R["g"].g_lo:R["g"].nxl - R["g"].g_hi, :d["nze"]].cpu().numpy()
     assert_bit_equal(np.concatenate([own(R, "dpp") for R in ranks]), oPP, "slab PP")
     assert_bit_equal(np.concatenate([own(R, "dp") for R in ranks]), oP, "slab P")
+
+
+@pytest.mark.parametrize("world,ksteps,overlap", [(2, 4, True), (3, 3, True), (2, 2, False)])
+def test_slabforward_driver_in_lockstep_on_one_gpu(world, ksteps, overlap):
+    """decomp.SlabForward itself (C-side cycle stepping, strip/interior split of the overlapped exchange) for
+    several slabs on ONE GPU: the cycle generators are advanced in lockstep and the halo exchange at their
+    yield points is done with in-process copies.  Bit-identical to the oracle's single-domain run."""
+    import torch
+    from parallel_finite_difference_computation_amd.decomp import HipSlabStepper, SlabForward, SlabGeometry
+    d = make_deck(260, 300, 20, 24, 30, seed=14, compat=True)
+    nsteps = 2 * ksteps + 1 + ksteps     # full cycles (with a "mid" exchange) + a partial one
+    srce_h = O.ricker_wavelet(d["nt"], d["dt"], 30.0)
+    oP, oPP = mko(d).forward(d["v2"], d["sx"], d["sz"], srce_h, nsteps=nsteps)
+    dev = torch.device("cuda:0")
+    srce = torch.from_numpy(srce_h).to(dev)
+    fws = []
+    for r in range(world):
+        g = SlabGeometry(r, world, d["nxe"], 4, ksteps)
+        ctx = mk(d, slab=(g.x_off, g.nxl))
+        a = torch.zeros((g.nxl, ctx.pitch), device=dev)
+        b = torch.zeros((g.nxl, ctx.pitch), device=dev)
+        v2 = torch.zeros((g.nxl, ctx.pitch), device=dev)
+        v2[:, :d["nze"]] = torch.from_numpy(d["v2"][g.x_off:g.x_off + g.nxl]).to(dev)
+        fw = SlabForward(g, HipSlabStepper(ctx), (a, b), v2, srce, d["sx"], d["sz"], overlap=overlap)
+        fw._ctx = ctx
+        fws.append(fw)
+    ts = torch.cuda.Stream()
+
+    def exchange_all():
+        for r, fw in enumerate(fws):
+            g = fw.g
+            for mine, theirs in ((fw.a, "a"), (fw.b, "b")):
+                if g.has_lo:
+                    s0, s1 = fws[r - 1].g.send_hi()
+                    mine[slice(*g.recv_lo())] = getattr(fws[r - 1], theirs)[s0:s1]
+                if g.has_hi:
+                    s0, s1 = fws[r + 1].g.send_lo()
+                    mine[slice(*g.recv_hi())] = getattr(fws[r + 1], theirs)[s0:s1]
+
+    with torch.cuda.stream(ts):
+        done, fresh = 0, False
+        while done < nsteps:
+            kk = min(ksteps, nsteps - done)
+            gens = [fw.cycle(kk, done + kk < nsteps, ts.cuda_stream) for fw in fws]
+            while True:
+                tags = [next(gn, None) for gn in gens]
+                assert len(set(tags)) == 1, tags
+                if tags[0] is None:
+                    break
+                if tags[0] == "pre":
+                    if not fresh:
+                        exchange_all()
+                    fresh = False
+                else:
+                    exchange_all()
+                    fresh = True
+            done += kk
+        for fw in fws:
+            fw._ctx.dev_taper_finalize(fw.d_p.data_ptr(), stream=ts.cuda_stream)
+    torch.cuda.synchronize()
+    own = lambda fw, f: fw.owned(f)[:, :d["nze"]].cpu().numpy()
+    assert_bit_equal(np.concatenate([own(fw, fw.d_pp) for fw in fws]), oPP, "SlabForward PP")
+    assert_bit_equal(np.concatenate([own(fw, fw.d_p) for fw in fws]), oP, "SlabForward P")
