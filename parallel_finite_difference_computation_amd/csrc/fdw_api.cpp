@@ -291,11 +291,12 @@ static void fill_geometry(const fdw_ctx* c, StepArgs& a, int rows)
         // halo rows a neighbouring chunk re-reads come from L2 / Infinity Cache, not HBM).
         //   HBM-resident grids (>= 8192^2): one ring turn (10 rows at prefetch 2)
         //   Infinity-Cache-resident grids (4096^2): 24 rows
-        //   small decks: 8 rows (latency bound; as many waves as possible)
+        //   small decks (new_mod 415x295 ... 2048^2): as many waves as the grid gives, down to ONE row per
+        //   wave -- a launch is a latency chain (prologue + rows), 5.1 us/step at 1 row vs 12.7 at 8 on new_mod
         const long strip_rows = (long)rows * nstrips;
         if (strip_rows >= 200000) xchunk = ring_rows(c->h, effective_prefetch(c));
         else if (strip_rows >= 32768) xchunk = 24;
-        else xchunk = 8;
+        else xchunk = (int)std::min<long>(std::max<long>((strip_rows + 4095) / 4096, 1), 8);   // >= ~4096 waves, down to 1 row each
     }
     a.xchunk = xchunk;
     a.wz = wz;

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""RTM timing probe (development tool): (a) the new_mod deck end to end through bin/rtm_code with a synthetic
+gather, (b) per-iteration time of the backward loop on large grids through the C ABI (fdw_shot)."""
+import os, subprocess, sys, tempfile, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import parallel_finite_difference_computation_amd as F
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+G = os.path.join(ROOT, "tests", "golden")
+
+def new_mod_program():
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "models", "new_mod")); os.makedirs(os.path.join(td, "output"))
+        vk = np.fromfile(os.path.join(G, "new_mod_vel_koslov.f32"), np.float32)
+        vk.tofile(os.path.join(td, "models", "new_mod", "vel-koslov.1"))
+        rng = np.random.default_rng(0)
+        rng.standard_normal(6 * 315 * 1700).astype(np.float32).tofile(os.path.join(td, "models", "new_mod", "dobs.6"))
+        deck = open(os.path.join(G, "decks", "new_mod.dat")).read().replace("vel_ext_file=./models/new_mod/vel_ext_rnd.6\n", "")
+        open(os.path.join(td, "input.dat"), "w").write(deck)
+        t0 = time.perf_counter()
+        r = subprocess.run([os.path.join(ROOT, "parallel_finite_difference_computation_amd", "bin", "rtm_code"), "./input.dat"], cwd=td, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        print("rtm_code new_mod (6 shots x (1700 fwd + 1700 bwd) steps, 415x295):", f"{dt:.2f} s wall;", r.stdout.strip().splitlines()[-1], flush=True)
+
+def big(n, nt):
+    nb = 64
+    ctx = F.FDWave(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 1e-3, compat=False)
+    rng = np.random.default_rng(0)
+    v2 = np.full((n, n), 2500.0 ** 2, np.float32)
+    d_obs = rng.standard_normal((n - 2 * nb, nt)).astype(np.float32)
+    srce = F.ricker_wavelet(nt, 1e-3, 20.0)
+    ctx.shot(v2, n // 2, nb + 2, nb + 2, srce, d_obs)          # warm (allocations)
+    t0 = time.perf_counter(); ctx.shot(v2, n // 2, nb + 2, nb + 2, srce, d_obs); t1 = time.perf_counter()
+    ctx2 = F.FDWave(8, n, n, nb, nb, 2 * nt, 0.75, 10.0, 10.0, 1e-3, compat=False)
+    d2 = rng.standard_normal((n - 2 * nb, 2 * nt)).astype(np.float32)
+    s2 = F.ricker_wavelet(2 * nt, 1e-3, 20.0)
+    ctx2.shot(v2, n // 2, nb + 2, nb + 2, s2, d2)
+    t2 = time.perf_counter(); ctx2.shot(v2, n // 2, nb + 2, nb + 2, s2, d2); t3 = time.perf_counter()
+    per = ((t3 - t2) - (t1 - t0)) / nt            # one forward step + one backward iteration
+    print(f"n={n}: forward step + backward iteration = {per*1e6:.1f} us  -> {n*n/per/1e9:.1f} Gpt/s per (fwd+bwd) pair, "
+          f"{n*n*(16+44)/per/1e12:.2f} TB/s algorithmic (16 + 44 B/pt)", flush=True)
+
+if __name__ == "__main__":
+    new_mod_program()
+    for n in (4096, 8192):
+        big(n, 60)
