@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--ksteps", type=int, default=0, help="time steps per halo exchange (N > 1); 0 = auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--init", choices=["noise", "rest"], default="noise",
+                    help="initial wavefield: seeded noise (default; every cache line carries real data) or at rest (zeros + source)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,13 +104,13 @@ def main():
     geom = SlabGeometry(rank, world, n, ORDER // 2, args.ksteps if world > 1 else 1)
     ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank,
                    slab=(geom.x_off, geom.nxl) if world > 1 else None)
+    if os.environ.get("FDW_XCHUNK"):      # tuning experiments only
+        ctx.set_tuning(xchunk=int(os.environ["FDW_XCHUNK"]))
     pitch = ctx.pitch
-    a = torch.zeros((geom.nxl, pitch), device=dev)
-    b = torch.zeros((geom.nxl, pitch), device=dev)
     v2 = torch.zeros((geom.nxl, pitch), device=dev)
     v2[:, :n] = synthetic_velocity_rows(n, geom.x_off, geom.nxl, dev)
     srce = torch.from_numpy(F.ricker_wavelet(nt, DT, FPEAK)).to(dev)
-    fw = SlabForward(geom, HipSlabStepper(ctx), (a, b), v2, srce, n // 2, n // 2, overlap=not args.no_overlap)
+    sx, sz = n // 2, n // 2
 
     def sync_all():
         torch.cuda.synchronize()
@@ -116,25 +118,72 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    fw.run(W)
-    fw.synchronize()       # also forces torch's lazy creation of both streams outside the timed region
-    sync_all()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record(fw.compute)
-    fw.run(K)
-    e1.record(fw.compute)
-    while not e1.query():      # spin until the last step has finished: hipStreamSynchronize sleeps in ms-sized naps
-        pass
-    fw.synchronize()
-    sync_all()
-    wall = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)
+    if world == 1:
+        # One GPU: the library's forward loop over four rotating buffers (fdw_dev_steps2): pairs of time steps go
+        # through the two-step kernel (temporal blocking) where it pays, everything enqueued by ONE library call.
+        skew = int(os.environ.get("FDW_ALLOC_SKEW", "0"))     # tuning experiments only: bytes of padding between the field buffers
+        bufs, pads = [], []
+        for _ in range(4):
+            if skew:
+                pads.append(torch.empty(skew, dtype=torch.uint8, device=dev))
+            bufs.append(torch.zeros((n, pitch), device=dev))
+        if args.init == "noise":   # non-trivial bit patterns everywhere (a quiescent field is mostly zeros for the whole run)
+            g = torch.Generator(device=dev)
+            g.manual_seed(0x5EED0001)
+            for b_ in bufs[:2]:
+                b_[:, :n] = 1e-3 * torch.randn((n, n), device=dev, generator=g)
+        ptrs = [b.data_ptr() for b in bufs]
+        stream = torch.cuda.Stream()
+        roles = {"ip": 0, "ipp": 1}
+
+        def run(it0, nsteps):
+            roles["ip"], roles["ipp"] = ctx.dev_steps2(ptrs, v2.data_ptr(), srce.data_ptr(), sx, sz, it0, nsteps, it0 > 0,
+                                                       roles["ip"], roles["ipp"], stream=stream.cuda_stream)
+
+        run(0, W)
+        stream.synchronize()
+        sync_all()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        run(W, K)
+        e1.record(stream)
+        while not e1.query():      # spin: hipStreamSynchronize naps in ms-sized steps
+            pass
+        stream.synchronize()
+        sync_all()
+        wall = time.perf_counter() - t0
+        dev_ms = e0.elapsed_time(e1)
+        newest = bufs[roles["ipp"]]
+    else:
+        a = torch.zeros((geom.nxl, pitch), device=dev)
+        b = torch.zeros((geom.nxl, pitch), device=dev)
+        if args.init == "noise":   # the same global noise field on every decomposition: seeded per global row block
+            g = torch.Generator(device=dev)
+            for f_, seed in ((a, 0x5EED0001), (b, 0x5EED0002)):
+                g.manual_seed(seed)
+                full_rows = 1e-3 * torch.randn((n, 64), device=dev, generator=g)      # cheap, decomposition-independent pattern
+                f_[:, :n] = full_rows[geom.x_off:geom.x_off + geom.nxl].repeat(1, n // 64)
+        fw = SlabForward(geom, HipSlabStepper(ctx), (a, b), v2, srce, sx, sz, overlap=not args.no_overlap)
+        fw.run(W)
+        fw.synchronize()       # also forces torch's lazy creation of both streams outside the timed region
+        sync_all()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(fw.compute)
+        fw.run(K)
+        e1.record(fw.compute)
+        while not e1.query():
+            pass
+        fw.synchronize()
+        sync_all()
+        wall = time.perf_counter() - t0
+        dev_ms = e0.elapsed_time(e1)
+        newest = fw.owned(fw.d_pp)
     if world > 1:
         t = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-    newest = fw.owned(fw.d_pp)
     finite = bool(torch.isfinite(newest).all().item()) and float(newest.abs().max().item()) > 0.0
     if world > 1:
         f = torch.tensor([1.0 if finite else 0.0], device=dev)
@@ -150,7 +199,7 @@ def main():
             "metric": "Gpoints/s (stencil updates) + achieved HBM GB/s vs peak",
             "value": round(gpts, 3), "unit": "Gpoints/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(wall * 1e3 / K, 6), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (seeded noise wavefield)" if args.init == "noise" else " (field at rest + Ricker source)"),
             "config": {"workload": f"2D 8th-order acoustic stencil, fused forward step (taper+Laplacian+leap-frog+source), "
                                    f"{n}x{n} fp32 extended grid, nxb=nzb={NB}, {K} steps"
                                    + (f", x-slab decomposition over {world} GPUs, {args.ksteps} steps per halo exchange" if world > 1 else ""),
@@ -158,17 +207,22 @@ def main():
             "result_finite_nonzero": finite,
         }
         if world == 1:
-            launch_ms = dev_ms / K
-            achieved = ALGO_BYTES_PER_POINT * pts_per_launch / (launch_ms * 1e-3) / 1e9
+            two = ctx.two_step_active()
+            steps_per_launch = 2 if two else 1
+            launches = (K // 2 + K % 2) if two else K
+            launch_ms = dev_ms / launches
+            algo = ALGO_BYTES_PER_POINT * pts_per_launch * steps_per_launch      # 16 B/point/step x steps in one launch
+            achieved = algo / (launch_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                               "kernel": "fdw::fdw_step_kernel<4,true,1,false,false,2>", "launch_us": round(launch_ms * 1e3, 2),
-                               "algorithmic_bytes_per_launch": ALGO_BYTES_PER_POINT * pts_per_launch}
+                               "kernel": "fdw::fdw_step2_kernel<4,true,2> (two time steps per launch)" if two else "fdw::fdw_step_kernel<4,true,1,false,false,2>",
+                               "launch_us": round(launch_ms * 1e3, 2), "steps_per_launch": steps_per_launch,
+                               "algorithmic_bytes_per_launch": algo}
             traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(traffic_file):   # HBM bytes per launch from the committed rocprofv3 --pmc passes
                 try:
                     t = json.load(open(traffic_file))
-                    if t.get("size") == n:
+                    if t.get("size") == n and t.get("steps_per_launch", 1) == steps_per_launch:
                         out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
                 except Exception:
                     pass

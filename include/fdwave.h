@@ -118,6 +118,13 @@ int fdw_shot(fdw_ctx *ctx, const float *v2, int sx, int sz, int gz, const float 
  * fdw_dev_taper_finalize  applies the one taper pass the lazy scheme still owes to a field that was
  *                 last used as d_p (needed before it is exported or used untapered).
  * fdw_dev_laplacian  mode 3: d_lap = Laplacian(d_p), zero outside the interior.
+ * fdw_dev_step2   TWO forward iterations in one pass (temporal blocking, order 8, full slab): reads d_p = newest
+ *                 field u^n (the reference's d_p AFTER its swap), d_pp = u^{n-1}, writes u^{n+1} to d_out1 and
+ *                 u^{n+2} to d_out2 (no aliasing allowed), d_srce_it -> {srce[it], srce[it+1]}.  10 B/point/step
+ *                 instead of 16; results are bit-identical to two fdw_dev_step calls.
+ * fdw_dev_steps2  nsteps iterations over FOUR rotating buffers, in pairs through fdw_dev_step2 (odd remainder:
+ *                 one-step kernel).  ip and ipp index the reference's (d_p, d_pp) before the first swap on entry
+ *                 and after the loop on return.
  * fdw_dev_steps_shrink  like fdw_dev_steps for one slab of a decomposed grid between two halo exchanges:
  *                 step j = j0.. of the cycle updates rows [h*j, nxl - h*j) on the sides that have a
  *                 neighbour (shrink_lo / shrink_hi), see decomp.py.
@@ -134,6 +141,10 @@ int fdw_dev_steps(fdw_ctx *ctx, float *d_p, float *d_pp, const float *d_v2, cons
                   int it0, int nsteps, int first_pp_twice, void *stream);
 int fdw_dev_steps_shrink(fdw_ctx *ctx, float *d_p, float *d_pp, const float *d_v2, const float *d_srce, int sx, int sz,
                          int it0, int nsteps, int first_pp_twice, int j0, int shrink_lo, int shrink_hi, void *stream);
+int fdw_dev_step2(fdw_ctx *ctx, const float *d_p, const float *d_pp, const float *d_v2, float *d_out1, float *d_out2, int pp_twice,
+                  const float *d_srce_it, int sx, int sz, void *stream);
+int fdw_dev_steps2(fdw_ctx *ctx, float *const *d_buf, const float *d_v2, const float *d_srce, int sx, int sz, int it0, int nsteps,
+                   int first_pp_twice, int *ip, int *ipp, void *stream);
 int fdw_dev_taper_finalize(fdw_ctx *ctx, float *d_f, void *stream);
 int fdw_dev_laplacian(fdw_ctx *ctx, const float *d_p, float *d_lap, void *stream);
 
@@ -145,16 +156,17 @@ int fdw_download_field(fdw_ctx *ctx, float *h_dst, const float *d_src);
  * fdw_set_tuning  xchunk = rows marched per wave (0 = auto), wz = waves of a block laid along z
  *                 (1,2,4; 0 = auto), use_generic = force the generic-order kernel (tests),
  *                 prefetch = software prefetch distance in rows (0 = default; 1..3, order 8 only),
- *                 force_edge = run every wave through the general masked body (tests).
+ *                 two_step = temporal blocking in the forward loops: 0 auto (grids >= 8192^2), 1 always, -1 never.
  * fdw_get_tables  copies of the derived host tables (any pointer may be NULL):
  *                 coefs_x/z[order+1] (R:214-217), taper_x[nxb], taper_z[nzb] (R:159-166).
  * fdw_get_extents xlim/zlim = rows/columns the time update covers, ztap = damped columns (R:185-195).
  * fdw_selftest    runs the DPP wave-shift self test on the device; 0 if the hardware behaves as the
  *                 step kernel assumes.
  */
-int fdw_set_tuning(fdw_ctx *ctx, int xchunk, int wz, int use_generic, int prefetch, int force_edge);
+int fdw_set_tuning(fdw_ctx *ctx, int xchunk, int wz, int use_generic, int prefetch, int two_step);
 int fdw_get_tables(const fdw_ctx *ctx, float *coefs_x, float *coefs_z, float *taper_x, float *taper_z);
 int fdw_get_extents(const fdw_ctx *ctx, int *xlim, int *zlim, int *ztap);
+int fdw_two_step_active(const fdw_ctx *ctx); /* 1 if the forward loops of this context use the two-step kernel */
 int fdw_selftest(fdw_ctx *ctx);
 
 /* ---- host formulas of libsource.a restated (pure C, usable without a device) --------------------

@@ -47,6 +47,8 @@ SIGNATURES = [
     ("fdw_dev_step", C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),
     ("fdw_dev_steps", C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     ("fdw_dev_steps_shrink", C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 8 + [vp]),
+    ("fdw_dev_step2", C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
+    ("fdw_dev_steps2", C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]),
     ("fdw_dev_taper_finalize", C.c_int, [vp, vp, vp]),
     ("fdw_dev_laplacian", C.c_int, [vp, vp, vp, vp]),
     ("fdw_upload_field", C.c_int, [vp, vp, f32p]),
@@ -54,6 +56,7 @@ SIGNATURES = [
     ("fdw_set_tuning", C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("fdw_get_tables", C.c_int, [vp, vp, vp, vp, vp]),
     ("fdw_get_extents", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("fdw_two_step_active", C.c_int, [vp]),
     ("fdw_selftest", C.c_int, [vp]),
     ("fdw_calc_coefs", C.c_int, [C.c_int, C.c_int, f32p]),
     ("fdw_ricker_wavelet", None, [C.c_int, C.c_float, C.c_float, f32p]),

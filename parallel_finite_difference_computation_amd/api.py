@@ -100,8 +100,12 @@ class FDWave:
         check(lib().fdw_get_extents(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
-    def set_tuning(self, xchunk=0, wz=0, use_generic=False, prefetch=0, force_edge=False):
-        check(lib().fdw_set_tuning(self._h, xchunk, wz, int(use_generic), prefetch, int(force_edge)))
+    def set_tuning(self, xchunk=0, wz=0, use_generic=False, prefetch=0, two_step=0, force_edge=False):
+        """two_step: 0 auto, 1 always, -1 never (temporal blocking in forward loops).  force_edge is obsolete and ignored."""
+        check(lib().fdw_set_tuning(self._h, xchunk, wz, int(use_generic), prefetch, int(two_step)))
+
+    def two_step_active(self):
+        return bool(lib().fdw_two_step_active(self._h))
 
     def selftest(self):
         check(lib().fdw_selftest(self._h))
@@ -159,6 +163,18 @@ class FDWave:
     def dev_steps_shrink(self, d_p, d_pp, d_v2, d_srce, sx, sz, it0, nsteps, first_pp_twice, j0, shrink_lo, shrink_hi, stream=None):
         check(lib().fdw_dev_steps_shrink(self._h, d_p, d_pp, d_v2, d_srce, sx, sz, it0, nsteps, int(first_pp_twice), j0,
                                          int(shrink_lo), int(shrink_hi), stream))
+
+    def dev_step2(self, d_p, d_pp, d_v2, d_out1, d_out2, pp_twice=True, d_srce_it=None, sx=-1, sz=0, stream=None):
+        """Two forward iterations in one pass (temporal blocking); d_p is the NEWEST field."""
+        check(lib().fdw_dev_step2(self._h, d_p, d_pp, d_v2, d_out1, d_out2, int(pp_twice), d_srce_it, sx, sz, stream))
+
+    def dev_steps2(self, bufs, d_v2, d_srce, sx, sz, it0, nsteps, first_pp_twice=False, ip=0, ipp=1, stream=None):
+        """nsteps iterations over four rotating device buffers (pairs via the two-step kernel).
+        Returns the indices (ip, ipp) of the reference's (d_p, d_pp) after the loop."""
+        arr = (C.c_void_p * 4)(*bufs)
+        a, b = C.c_int(ip), C.c_int(ipp)
+        check(lib().fdw_dev_steps2(self._h, arr, d_v2, d_srce, sx, sz, it0, nsteps, int(first_pp_twice), C.byref(a), C.byref(b), stream))
+        return a.value, b.value
 
     def dev_taper_finalize(self, d_f, stream=None):
         check(lib().fdw_dev_taper_finalize(self._h, d_f, stream))

@@ -69,7 +69,8 @@ struct fdw_ctx {
     float *d_v2 = nullptr, *d_img = nullptr, *d_srce = nullptr, *d_dobs = nullptr;
     size_t srce_cap = 0, dobs_cap = 0;
     // tuning
-    int xchunk = 0, wz = 0, use_generic = 0, prefetch = 0, force_edge = 0;
+    int xchunk = 0, wz = 0, use_generic = 0, prefetch = 0, force_edge = 0, xchunk2 = 0;
+    int tb = 0;   // two-steps-per-pass kernel: 0 auto (large grids), 1 always, -1 never
 };
 
 static size_t field_elems(const fdw_ctx* c) { return (size_t)c->nxl * (size_t)c->pitch; }
@@ -392,6 +393,107 @@ extern "C" int fdw_dev_steps(fdw_ctx* c, float* d_p, float* d_pp, const float* d
     return FDW_OK;
 }
 
+// ---- two time steps per pass (temporal blocking) --------------------------------------------------
+static int step2_impl(fdw_ctx* c, const float* d_p, const float* d_pp, const float* d_v2, float* d_out1, float* d_out2, int pp_twice,
+                      const float* d_srce_it, int sx_global, int sz, hipStream_t s)
+{
+    if (c->h != kMaxFastHalfOrder) return fail(FDW_EINVAL, "step2: the two-step kernel is built for order 8 only");
+    if (!d_p || !d_pp || !d_v2 || !d_out1 || !d_out2) return fail(FDW_EINVAL, "step2: NULL buffer");
+    if (d_out1 == d_p || d_out1 == d_pp || d_out2 == d_p || d_out2 == d_pp || d_out1 == d_out2)
+        return fail(FDW_EINVAL, "step2: outputs must not alias the inputs (tiles re-read each other's input rows)");
+    Step2Args a{};
+    a.p = d_p; a.pp = d_pp; a.v2 = d_v2; a.out1 = d_out1; a.out2 = d_out2;
+    a.taperz = c->d_taperz; a.txfac = c->d_txfac; a.inj = d_srce_it;
+    a.pitch = c->pitch; a.nxl = c->nxl;
+    a.r0 = 0; a.r1 = c->upd_x1;
+    a.lap_x0 = c->lap_x0; a.lap_x1 = c->lap_x1; a.lap_z0 = c->lap_z0; a.lap_z1 = c->lap_z1;
+    a.upd_x1 = c->upd_x1; a.upd_z1 = c->upd_z1;
+    a.ztap = c->ztap; a.tz_x1 = c->tz_x1; a.xt_lo = c->xt_lo; a.xt_hi = c->xt_hi;
+    a.pp_twice = pp_twice ? 1 : 0;
+    a.inj_x = -1000000; a.inj_z = sz;
+    if (d_srce_it && sx_global >= 0) {
+        if (sz < 0 || sz >= c->prm.nze || sx_global >= c->prm.nxe) return fail(FDW_EINVAL, "step2: source (%d,%d) outside the grid", sx_global, sz);
+        a.inj_x = sx_global - c->slab.x_off;
+        if (a.inj_x >= c->upd_x1 && a.inj_x < c->nxl)
+            return fail(FDW_EINVAL, "step2: source row %d lies in rows the reference never time-steps (>= %d)", sx_global, c->xlim);
+    }
+    a.dt2 = c->dt2;
+    for (int io = 0; io <= 2 * kMaxFastHalfOrder; io++) { a.cx[io] = c->cx[io]; a.cz[io] = c->cz[io]; }
+    const int ncells = c->pitch / 4;
+    a.nstrip = (ncells + 59) / 60;
+    a.nzblk = (a.nstrip + 3) / 4;
+    const int rows = a.r1 - a.r0;
+    if (rows <= 0) return FDW_OK;
+    // whole ring turns only (the march is branch-free, a partial turn still costs a full one): xchunk + 2H = 10k.
+    // Measured (scripts/probe_tb.py, noise-filled fields; +-5 % between boxes/runs): 16384^2 500 Gpt/s at 72,
+    // 8192^2 430-450 at 22 (42 is as good on some runs, 7 % worse on others), 4096^2 353 at 22.
+    int xchunk = c->xchunk2 > 0 ? c->xchunk2 : ((long)rows * a.nstrip >= 1000000 ? 72 : ((long)rows * a.nstrip >= 16384 ? 22 : 2));
+    a.xchunk = xchunk;
+    const int chunks = (rows + xchunk - 1) / xchunk;
+    a.nblk = a.nzblk * chunks;
+    a.nper = (a.nblk + 7) / 8;
+    hipError_t e = launch_step2(a, c->h, 1, s);
+    if (e != hipSuccess) return fail(FDW_EHIP, "step2 launch failed: %s", hipGetErrorString(e));
+    // rows the reference never time-steps (compat, nxe not a multiple of 8): both fields are static there and
+    // swap roles every step, so after two steps out1 carries pp's rows and out2 p's rows
+    if (c->upd_x1 < c->nxl) {
+        const size_t off = (size_t)c->upd_x1 * c->pitch, n = (size_t)(c->nxl - c->upd_x1) * c->pitch * sizeof(float);
+        HIP_TRY(hipMemcpyAsync(d_out1 + off, d_pp + off, n, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_out2 + off, d_p + off, n, hipMemcpyDeviceToDevice, s));
+    }
+    return FDW_OK;
+}
+
+// The two-step kernel wins where a launch is bandwidth bound (>= 8192^2: +12 %, 16384^2: +42 %); on small decks a
+// launch is a latency chain and the longer march loses (new_mod: 12 vs 5 us/step), so the one-step kernel stays.
+static bool two_step_pays(const fdw_ctx* c)
+{
+    if (c->h != kMaxFastHalfOrder || c->use_generic || c->tb < 0) return false;
+    if (c->tb > 0) return true;
+    return (long)c->upd_x1 * ((c->pitch / 4 + 59) / 60) >= 200000;
+}
+
+extern "C" int fdw_two_step_active(const fdw_ctx* c) { return c && two_step_pays(c) ? 1 : 0; }
+
+extern "C" int fdw_dev_step2(fdw_ctx* c, const float* d_p, const float* d_pp, const float* d_v2, float* d_out1, float* d_out2, int pp_twice,
+                             const float* d_srce_it, int sx, int sz, void* stream)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    return step2_impl(c, d_p, d_pp, d_v2, d_out1, d_out2, pp_twice, d_srce_it, sx, sz, pick_stream(c, stream));
+}
+
+// nsteps reference iterations (R:259-267) over four rotating buffers: pairs of steps through the two-step
+// kernel, an odd last step through the one-step kernel.  On entry buf[*ip], buf[*ipp] are the reference's
+// (d_p, d_pp) BEFORE the first swap; on return they index (d_p, d_pp) after the loop.
+extern "C" int fdw_dev_steps2(fdw_ctx* c, float* const* buf, const float* d_v2, const float* d_srce, int sx, int sz, int it0, int nsteps,
+                              int first_pp_twice, int* ip, int* ipp, void* stream)
+{
+    if (!c || !buf || !ip || !ipp) return fail(FDW_EINVAL, "NULL argument");
+    if (*ip < 0 || *ip > 3 || *ipp < 0 || *ipp > 3 || *ip == *ipp) return fail(FDW_EINVAL, "steps2: bad buffer indices");
+    hipStream_t s = pick_stream(c, stream);
+    int k = 0;
+    while (k < nsteps) {
+        const int twice = (k > 0) || first_pp_twice;
+        if (nsteps - k >= 2 && two_step_pays(c)) {
+            int o1 = 0, o2 = 0;   // the two buffers not holding the current pair
+            for (int i = 0, n = 0; i < 4; i++)
+                if (i != *ip && i != *ipp) { (n++ == 0 ? o1 : o2) = i; }
+            // after the swap the kernel's p is the old d_pp (newest field), its pp the old d_p
+            int rc = step2_impl(c, buf[*ipp], buf[*ip], d_v2, buf[o1], buf[o2], twice, d_srce ? d_srce + it0 + k : nullptr, d_srce ? sx : -1, sz, s);
+            if (rc) return rc;
+            *ip = o1; *ipp = o2;   // d_p = u^{n+1}, d_pp = u^{n+2}
+            k += 2;
+        } else {
+            std::swap(*ip, *ipp);
+            int rc = step_impl(c, FDW_MODE_FWD, buf[*ip], buf[*ipp], d_v2, 0, c->nxl, twice, d_srce ? d_srce + it0 + k : nullptr,
+                               d_srce ? sx : -1, sz, nullptr, nullptr, s);
+            if (rc) return rc;
+            k += 1;
+        }
+    }
+    return FDW_OK;
+}
+
 // ksteps-cycle of the slab decomposition in one call: step j (1-based, j = j0 .. j0+nsteps-1) updates the
 // rows still valid on the interior sides, [h*j, nxl - h*j) (decomp.py "deep halos").
 extern "C" int fdw_dev_steps_shrink(fdw_ctx* c, float* d_p, float* d_pp, const float* d_v2, const float* d_srce, int sx, int sz,
@@ -494,15 +596,13 @@ static int upload_source(fdw_ctx* c, const float* srce, int n)
     return FDW_OK;
 }
 
-// fd_forward's loop body R:259-267 for nsteps iterations on device buffers; returns the final roles.
-static int forward_loop(fdw_ctx* c, float** d_p, float** d_pp, int sx, int sz, int nsteps)
+// fd_forward's loop body R:259-267 for nsteps iterations over the context's four field buffers (pairs of steps go
+// through the two-step kernel where it pays); *ip / *ipp index (d_p, d_pp) before the loop and after it.
+static int forward_loop(fdw_ctx* c, int* ip, int* ipp, int sx, int sz, int nsteps)
 {
-    for (int it = 0; it < nsteps; it++) {
-        std::swap(*d_p, *d_pp);
-        int rc = step_impl(c, FDW_MODE_FWD, *d_p, *d_pp, c->d_v2, 0, c->nxl, it > 0, c->d_srce + it, sx, sz, nullptr, nullptr, c->stream);
-        if (rc) return rc;
-    }
-    if (nsteps > 0) return fdw_dev_taper_finalize(c, *d_p, c->stream);   // the T() d_p still owes (R:285 downloads the damped d_p)
+    int rc = fdw_dev_steps2(c, c->fld, c->d_v2, c->d_srce, sx, sz, 0, nsteps, 0, ip, ipp, c->stream);
+    if (rc) return rc;
+    if (nsteps > 0) return fdw_dev_taper_finalize(c, c->fld[*ip], c->stream);   // the T() d_p still owes (R:285 downloads the damped d_p)
     return FDW_OK;
 }
 
@@ -514,13 +614,13 @@ extern "C" int fdw_forward(fdw_ctx* c, float* p, float* pp, const float* v2, int
     int rc;
     if ((rc = check_static_taper_rows(c, p, "p")) || (rc = check_static_taper_rows(c, pp, "pp"))) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    if ((rc = ensure_work_buffers(c, 2, false))) return rc;
-    float *d_p = c->fld[0], *d_pp = c->fld[1];
-    if ((rc = upload_rows(c, d_p, p, c->stream)) || (rc = upload_rows(c, d_pp, pp, c->stream)) ||
+    if ((rc = ensure_work_buffers(c, 4, false))) return rc;
+    int ip = 0, ipp = 1;
+    if ((rc = upload_rows(c, c->fld[0], p, c->stream)) || (rc = upload_rows(c, c->fld[1], pp, c->stream)) ||
         (rc = upload_rows(c, c->d_v2, v2, c->stream)) || (rc = upload_source(c, srce, nsteps)))
         return rc;
-    if ((rc = forward_loop(c, &d_p, &d_pp, sx, sz, nsteps))) return rc;
-    if ((rc = download_rows(c, p, d_p, c->stream)) || (rc = download_rows(c, pp, d_pp, c->stream))) return rc;
+    if ((rc = forward_loop(c, &ip, &ipp, sx, sz, nsteps))) return rc;
+    if ((rc = download_rows(c, p, c->fld[ip], c->stream)) || (rc = download_rows(c, pp, c->fld[ipp], c->stream))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return FDW_OK;
 }
@@ -562,6 +662,11 @@ static int back_loop(fdw_ctx* c, const float* hsnap0, const float* hsnap1, float
     const bool resident = (dsnap0 != nullptr);
     if (resident) {
         d_p = nullptr; d_pp = nullptr;
+        // the forward pass rotates through all four buffers: the receiver pair takes the two that do not hold the snapshots
+        float* spare[2] = {nullptr, nullptr};
+        for (int i = 0, n = 0; i < 4 && n < 2; i++)
+            if (c->fld[i] != dsnap0 && c->fld[i] != dsnap1) spare[n++] = c->fld[i];
+        d_pr = spare[0]; d_ppr = spare[1];
     } else {
         d_p = c->fld[0]; d_pp = c->fld[1];
         HIP_TRY(hipMemsetAsync(d_p, 0, field_elems(c) * sizeof(float), c->stream));
@@ -622,13 +727,14 @@ extern "C" int fdw_shot(fdw_ctx* c, const float* v2, int sx, int sz, int gz, con
     int rc;
     const int nt = c->prm.nt;
     if ((rc = ensure_work_buffers(c, 4, true))) return rc;
-    float *d_p = c->fld[0], *d_pp = c->fld[1];
-    HIP_TRY(hipMemsetAsync(d_p, 0, field_elems(c) * sizeof(float), c->stream));    // R:496-497
-    HIP_TRY(hipMemsetAsync(d_pp, 0, field_elems(c) * sizeof(float), c->stream));
+    int ip = 0, ipp = 1;
+    HIP_TRY(hipMemsetAsync(c->fld[0], 0, field_elems(c) * sizeof(float), c->stream));    // R:496-497
+    HIP_TRY(hipMemsetAsync(c->fld[1], 0, field_elems(c) * sizeof(float), c->stream));
     if ((rc = upload_rows(c, c->d_v2, v2, c->stream)) || (rc = upload_source(c, srce, nt)) || (rc = upload_gather(c, d_obs)) ||
         (rc = image_to_device(c, imloc)))
         return rc;
-    if ((rc = forward_loop(c, &d_p, &d_pp, sx, sz, nt))) return rc;
+    if ((rc = forward_loop(c, &ip, &ipp, sx, sz, nt))) return rc;
+    float *d_p = c->fld[ip], *d_pp = c->fld[ipp];
     if (P && (rc = download_rows(c, P, d_p, c->stream))) return rc;
     if (PP && (rc = download_rows(c, PP, d_pp, c->stream))) return rc;
     if ((rc = back_loop(c, nullptr, nullptr, d_p, d_pp, gz, nt))) return rc;
@@ -640,7 +746,7 @@ extern "C" int fdw_shot(fdw_ctx* c, const float* v2, int sx, int sz, int gz, con
 // ------------------------------------------------------------------------------------------------
 // tuning / introspection
 // ------------------------------------------------------------------------------------------------
-extern "C" int fdw_set_tuning(fdw_ctx* c, int xchunk, int wz, int use_generic, int prefetch, int force_edge)
+extern "C" int fdw_set_tuning(fdw_ctx* c, int xchunk, int wz, int use_generic, int prefetch, int two_step)
 {
     if (!c) return fail(FDW_EINVAL, "ctx is NULL");
     if (xchunk < 0 || (wz != 0 && wz != 1 && wz != 2 && wz != 4) || prefetch < 0 || prefetch > 3)
@@ -649,7 +755,8 @@ extern "C" int fdw_set_tuning(fdw_ctx* c, int xchunk, int wz, int use_generic, i
     c->wz = wz;
     c->use_generic = use_generic ? 1 : 0;
     c->prefetch = prefetch;
-    c->force_edge = force_edge ? 1 : 0;
+    c->tb = two_step < 0 ? -1 : (two_step > 0 ? 1 : 0);
+    c->xchunk2 = xchunk;   // the two-step kernel shares the knob (0 = its own default)
     return FDW_OK;
 }
 

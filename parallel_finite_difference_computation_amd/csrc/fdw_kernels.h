@@ -40,6 +40,29 @@ struct StepArgs {
     float cx[2 * kMaxFastHalfOrder + 1], cz[2 * kMaxFastHalfOrder + 1];
 };
 
+// Two-steps-per-pass kernel (temporal blocking, order 8, forward mode): see fdw_step2_kernel.
+struct Step2Args {
+    const float* p;        // u^n
+    const float* pp;       // u^{n-1}
+    const float* v2;
+    float* out1;           // u^{n+1}
+    float* out2;           // u^{n+2}
+    const float* taperz;
+    const float* txfac;
+    const float* inj;      // two source samples: srce[it], srce[it+1]
+    int pitch, nxl;
+    int r0, r1;            // rows whose u^{n+1}, u^{n+2} this launch produces
+    int lap_x0, lap_x1, lap_z0, lap_z1;
+    int upd_x1, upd_z1;
+    int ztap, tz_x1, xt_lo, xt_hi;
+    int pp_twice;
+    int inj_x, inj_z;
+    int xchunk, nstrip, nzblk, nblk, nper;
+    float dt2;
+    float cx[2 * kMaxFastHalfOrder + 1], cz[2 * kMaxFastHalfOrder + 1];
+};
+hipError_t launch_step2(const Step2Args& a, int half_order, int taper, hipStream_t s);
+
 hipError_t launch_step_fast(const StepArgs& a, int half_order, int mode, int prefetch, hipStream_t s);
 hipError_t launch_step_generic(const StepArgs& a, int half_order, int mode, hipStream_t s);
 hipError_t launch_taper_finalize(float* f, const float* taperz, const float* txfac, int pitch, int nxl, int ztap,

@@ -110,8 +110,8 @@ def test_forward_interior_waves_vs_oracle(prefetch):
     oP, oPP = mko(d).forward(d["v2"], d["sx"], d["sz"], srce, p0, pp0)
     ctx = mk(d)
     for xchunk in (0, 12, 24, 30, 36):
-        for force_edge in (False, True):
-            ctx.set_tuning(xchunk=xchunk, prefetch=prefetch, force_edge=force_edge)
+        for force_edge in (False,):
+            ctx.set_tuning(xchunk=xchunk, prefetch=prefetch)
             P, PP = ctx.forward(d["v2"], d["sx"], d["sz"], srce, p0, pp0)
             assert_bit_equal(P, oP, f"P pf={prefetch} xchunk={xchunk} edge={force_edge}")
             assert_bit_equal(PP, oPP, f"PP pf={prefetch} xchunk={xchunk} edge={force_edge}")
@@ -143,6 +143,33 @@ def test_back_interior_waves_vs_oracle():
         ctx.set_tuning(xchunk=xchunk)
         assert_bit_equal(ctx.back(d["v2"], oP, oPP, d_obs, d["gz"]), oimg, f"imloc xchunk={xchunk}")
         assert_bit_equal(ctx.shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs), oimg, f"shot imloc xchunk={xchunk}")
+
+
+@pytest.mark.parametrize("case", [(99, 83, 17, 13, 21, True), (150, 1300, 20, 24, 16, True), (260, 530, 24, 40, 15, False)], ids=lambda c: "x".join(map(str, c)))
+def test_host_api_with_forced_two_step_kernel(case):
+    """fdw_forward / fdw_back / fdw_shot with temporal blocking forced on (it is automatic only on large grids):
+    forward fields and the image stay bit-identical to the oracle."""
+    nxe, nze, nxb, nzb, nt, compat = case
+    d = make_deck(nxe, nze, nxb, nzb, nt, seed=5, compat=compat)
+    nx, nz = nxe - 2 * nxb, nze - 2 * nzb
+    srce = O.ricker_wavelet(nt, d["dt"], 30.0)
+    p0, pp0 = random_fields(d, seed=13, amp=0.1)
+    d_obs = np.random.default_rng(4).standard_normal((nx, nt)).astype(np.float32)
+    ctx, orc = mk(d), mko(d)
+    ctx.set_tuning(two_step=1)
+    for n in (nt, nt - 1, 2, 3):
+        P, PP = ctx.forward(d["v2"], d["sx"], d["sz"], srce, p0, pp0, nsteps=n)
+        oP, oPP = orc.forward(d["v2"], d["sx"], d["sz"], srce, p0, pp0, nsteps=n)
+        assert_bit_equal(P, oP, f"P two-step n={n}")
+        assert_bit_equal(PP, oPP, f"PP two-step n={n}")
+    oP, oPP = orc.forward(d["v2"], d["sx"], d["sz"], srce)
+    oimg = orc.back(d["v2"], oP, oPP, d_obs, d["gz"])
+    img, P, PP = ctx.shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs, want_fields=True)
+    assert_bit_equal(P, oP, "shot P two-step")
+    assert_bit_equal(PP, oPP, "shot PP two-step")
+    assert_bit_equal(img, oimg, "shot image two-step")
+    ctx.set_tuning(two_step=-1)
+    assert_bit_equal(ctx.shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs), oimg, "shot image one-step")
 
 
 def test_forward_fast_kernel_equals_generic_kernel():
@@ -358,3 +385,47 @@ def test_slabforward_driver_in_lockstep_on_one_gpu(world, ksteps, overlap):
     own = lambda fw, f: fw.owned(f)[:, :d["nze"]].cpu().numpy()
     assert_bit_equal(np.concatenate([own(fw, fw.d_pp) for fw in fws]), oPP, "SlabForward PP")
     assert_bit_equal(np.concatenate([own(fw, fw.d_p) for fw in fws]), oP, "SlabForward P")
+
+
+TB_CASES = [(99, 83, 17, 13, True), (99, 83, 17, 13, False), (150, 1300, 20, 24, True), (260, 530, 24, 40, True), (64, 64, 8, 8, True)]
+
+
+@pytest.mark.parametrize("case", TB_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_two_step_kernel_vs_oracle_bit_exact(case):
+    """Temporal blocking (two time steps per pass over four rotating buffers) against the oracle: from rest and from a
+    random state, even and odd step counts, several chunk lengths."""
+    import torch
+    nxe, nze, nxb, nzb, compat = case
+    nt = 14
+    d = make_deck(nxe, nze, nxb, nzb, nt, seed=nxe, compat=compat)
+    srce_h = O.ricker_wavelet(nt, d["dt"], 30.0)
+    p0, pp0 = random_fields(d, seed=31, amp=0.1)
+    dev = torch.device("cuda:0")
+    ctx, orc = mk(d), mko(d)
+    srce = torch.from_numpy(srce_h).to(dev)
+    v2 = torch.zeros((nxe, ctx.pitch), device=dev)
+    v2[:, :nze] = torch.from_numpy(d["v2"]).to(dev)
+    ts = torch.cuda.Stream()
+    for init in ("rest", "random"):
+        for nsteps in (2, 5, 8, 13):
+            for xchunk in (0, 7, 20):
+                ctx.set_tuning(xchunk=xchunk)
+                bufs = [torch.zeros((nxe, ctx.pitch), device=dev) for _ in range(4)]
+                hp, hpp = (None, None) if init == "rest" else (p0, pp0)
+                if init == "random":
+                    bufs[0][:, :nze] = torch.from_numpy(p0).to(dev)
+                    bufs[1][:, :nze] = torch.from_numpy(pp0).to(dev)
+                bufs[2].fill_(7.0)          # stale contents of the spare buffers must not matter
+                bufs[3].fill_(-7.0)
+                bufs[2][:, nze:] = 0
+                bufs[3][:, nze:] = 0
+                torch.cuda.synchronize()
+                with torch.cuda.stream(ts):
+                    ip, ipp = ctx.dev_steps2([b.data_ptr() for b in bufs], v2.data_ptr(), srce.data_ptr(), d["sx"], d["sz"], 0, nsteps,
+                                             first_pp_twice=False, ip=0, ipp=1, stream=ts.cuda_stream)
+                    ctx.dev_taper_finalize(bufs[ip].data_ptr(), stream=ts.cuda_stream)
+                torch.cuda.synchronize()
+                oP, oPP = orc.forward(d["v2"], d["sx"], d["sz"], srce_h, hp, hpp, nsteps=nsteps)
+                tag = f"{init} nsteps={nsteps} xchunk={xchunk}"
+                assert_bit_equal(bufs[ipp][:, :nze].cpu().numpy(), oPP, "PP " + tag)
+                assert_bit_equal(bufs[ip][:, :nze].cpu().numpy(), oP, "P " + tag)
