@@ -160,8 +160,8 @@ int fdw_download_field(fdw_ctx *ctx, float *h_dst, const float *d_src);
  * fdw_get_tables  copies of the derived host tables (any pointer may be NULL):
  *                 coefs_x/z[order+1] (R:214-217), taper_x[nxb], taper_z[nzb] (R:159-166).
  * fdw_get_extents xlim/zlim = rows/columns the time update covers, ztap = damped columns (R:185-195).
- * fdw_selftest    runs the DPP wave-shift self test on the device; 0 if the hardware behaves as the
- *                 step kernel assumes.
+ * fdw_selftest    checks on the device the two hardware behaviours the kernels rely on (one-lane
+ *                 __shfl_up/down, range-predicated buffer stores); 0 if they are as assumed.
  */
 int fdw_set_tuning(fdw_ctx *ctx, int xchunk, int wz, int use_generic, int prefetch, int two_step);
 int fdw_get_tables(const fdw_ctx *ctx, float *coefs_x, float *coefs_z, float *taper_x, float *taper_z);

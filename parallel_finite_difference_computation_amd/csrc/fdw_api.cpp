@@ -783,23 +783,29 @@ extern "C" int fdw_selftest(fdw_ctx* c)
 {
     if (!c) return fail(FDW_EINVAL, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    float h_src[64], h_old[64], h_out[128];
-    for (int i = 0; i < 64; i++) { h_src[i] = 100.0f + i; h_old[i] = -1.0f - i; }
+    float h_src[64], h_out[384];
+    for (int i = 0; i < 64; i++) h_src[i] = 100.0f + i;
+    for (int i = 0; i < 384; i++) h_out[i] = -7.0f;
     float* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, 256 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&d, (64 + 384) * sizeof(float)));
     hipError_t e = hipMemcpy(d, h_src, sizeof h_src, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d + 64, h_old, sizeof h_old, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_dpp_selftest(d, d + 64, d + 128, c->stream);
+    if (e == hipSuccess) e = hipMemcpy(d + 64, h_out, sizeof h_out, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_selftest(d, d + 64, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMemcpy(h_out, d + 128, sizeof h_out, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_out, d + 64, sizeof h_out, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(FDW_EHIP, "selftest: %s", hipGetErrorString(e));
     for (int i = 0; i < 64; i++) {
-        const float want_r = i == 0 ? h_old[0] : h_src[i - 1];
-        const float want_l = i == 63 ? h_old[63] : h_src[i + 1];
-        if (h_out[i] != want_r || h_out[64 + i] != want_l)
-            return fail(FDW_EHIP, "selftest: DPP wave shift mismatch at lane %d (shr %g want %g, shl %g want %g)", i,
-                        (double)h_out[i], (double)want_r, (double)h_out[64 + i], (double)want_l);
+        const float up = i == 0 ? h_src[0] : h_src[i - 1], dn = i == 63 ? h_src[63] : h_src[i + 1];
+        if (h_out[i] != up || h_out[64 + i] != dn)
+            return fail(FDW_EHIP, "selftest: lane exchange mismatch at lane %d (up %g want %g, down %g want %g)", i,
+                        (double)h_out[i], (double)up, (double)h_out[64 + i], (double)dn);
+        for (int k = 0; k < 4; k++) {
+            const float want = (i >= 2 && i <= 61) ? h_src[i] : -7.0f;   // out-of-range lanes must leave memory alone
+            if (h_out[128 + 4 * i + k] != want)
+                return fail(FDW_EHIP, "selftest: range-predicated buffer store wrote %g at cell %d (want %g)",
+                            (double)h_out[128 + 4 * i + k], i, (double)want);
+        }
     }
     return FDW_OK;
 }

@@ -67,6 +67,6 @@ hipError_t launch_step_fast(const StepArgs& a, int half_order, int mode, int pre
 hipError_t launch_step_generic(const StepArgs& a, int half_order, int mode, hipStream_t s);
 hipError_t launch_taper_finalize(float* f, const float* taperz, const float* txfac, int pitch, int nxl, int ztap,
                                  int tz_x1, hipStream_t s);
-hipError_t launch_dpp_selftest(const float* src, const float* old, float* out, hipStream_t s);
+hipError_t launch_selftest(const float* src, float* out, hipStream_t s);
 
 }  // namespace fdw

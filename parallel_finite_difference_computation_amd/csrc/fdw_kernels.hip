@@ -10,15 +10,18 @@
 //   * a wave marches along x over `xchunk` rows keeping the rows of p it needs in a REGISTER ring
 //     (2H+1 stencil rows + look-ahead rows that are still in flight), so x taps never touch memory
 //     twice inside a chunk and HBM latency is covered by explicit software prefetch, not occupancy;
-//   * z taps come from the two neighbouring lanes by DPP wave shifts (v_mov_b32_dpp wave_shr:1 /
-//     wave_shl:1) of the centre row; only lanes 0 and 63 fetch a 16-B strip halo, in one
-//     exec-masked load whose result is the DPP `old` operand (so the merge is free);
+//   * z taps come from the two neighbouring lanes (ds_bpermute via __shfl_up/down by one lane; DPP
+//     wave shifts were measured 8 % slower on gfx950); the 4+4 halo columns of a strip come from ONE
+//     extra load issued by all lanes (lane 0 the left piece, every other lane the right piece);
 //   * taper, Laplacian, leap-frog update, point-source / receiver injection and the imaging
 //     condition are fused: p, pp, v2 are read once and pp written once = 16 B/point/step
-//     (+12 B/point for the imaging epilogue).  No LDS, no MFMA: the stencil is HBM-bound
-//     (about 2.5 flop/B), the register ring is the cheapest tile there is.
-//   * every wave picks one of two code paths: waves whose whole tile is interior run a mask-free
-//     body; waves touching a grid edge, the damped strip or an injection point run the general body.
+//     (+12 B/point for the imaging epilogue).  No MFMA: the stencil is HBM-bound (about 2.5 flop/B),
+//     the register ring is the cheapest tile there is;
+//   * every global load of the march is unconditional (clamped addresses instead of predication) so
+//     that hipcc's s_waitcnt bookkeeping stays exact (vmcnt(4..7), never 0); edge handling is
+//     wave-uniform branches around VALU / scalar-cache loads only;
+//   * fdw_step2_kernel does TWO time steps per pass (temporal blocking, 10 B/point/step): overlapped
+//     60-cell tiles, a second register ring for u^{n+1}, v2 rows parked in LDS, range-predicated stores.
 //
 // Arithmetic is the reference's, operation for operation, so results are IEEE-identical to the
 // no-FMA CUDA build (nvcc --fmad=false --ftz=false, Makefile:4): two fp32 accumulators summed
@@ -44,36 +47,11 @@ namespace fdw {
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-// lane n <- lane n-1; lane 0 keeps `old` (its strip halo).  DPP_WF_SR1 = 0x138.
-__device__ __forceinline__ float wave_shr1(float src, float old)
-{
-#if (defined(FDW_ABLATE) && FDW_ABLATE == 8) || (FDW_ABL_BITS & 8)
-    return src + old;
-#elif defined(FDW_ABLATE) && FDW_ABLATE == 9
-    { const float t = __shfl_up(src, 1, 64); return (threadIdx.x & 63) == 0 ? old : t; }
-#endif
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
-                                                                   __builtin_bit_cast(int, src),
-                                                                   0x138, 0xf, 0xf, false));
-}
-// lane n <- lane n+1; lane 63 keeps `old`.  DPP_WF_SL1 = 0x130.
-__device__ __forceinline__ float wave_shl1(float src, float old)
-{
-#if (defined(FDW_ABLATE) && FDW_ABLATE == 8) || (FDW_ABL_BITS & 8)
-    return src - old;
-#elif defined(FDW_ABLATE) && FDW_ABLATE == 9
-    { const float t = __shfl_down(src, 1, 64); return (threadIdx.x & 63) == 63 ? old : t; }
-#endif
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
-                                                                   __builtin_bit_cast(int, src),
-                                                                   0x130, 0xf, 0xf, false));
-}
-
-#ifndef FDW_ABLATE
-#define FDW_ABLATE 0   // timing experiments only (scripts/build_ablations.sh)
-#endif
+// Timing experiments only (scripts/build_ablations.sh builds throw-away libraries with -DFDW_ABL_BITS=n; any bit
+// breaks the results): 1 fp32 update, 2 no strip-halo load, 4 no store, 8 no lane exchange, 16 trivial Laplacian,
+// 32 every row aliases row 0 (loads become cache hits: pure issue/VALU time).
 #ifndef FDW_ABL_BITS
-#define FDW_ABL_BITS 0  // bitmask form: 1 f32 update, 2 no halo load, 4 no store, 8 no DPP, 16 trivial Laplacian
+#define FDW_ABL_BITS 0
 #endif
 
 struct f4 {
@@ -140,7 +118,7 @@ __device__ __forceinline__ float laplacian_pt(const float* W, int e, const float
                                               const float* cz)
 {
     float acmz = 0.0f, acmx = 0.0f;
-#if FDW_ABLATE == 11 || (FDW_ABL_BITS & 16)
+#if FDW_ABL_BITS & 16
     return W[e] + W[8 + e] + col[0] + col[2 * H];   // keep every input alive, almost no arithmetic
 #endif
 #pragma unroll
@@ -153,7 +131,7 @@ __device__ __forceinline__ float laplacian_pt(const float* W, int e, const float
 __device__ __forceinline__ float leapfrog_pt(float p, float pp, float v2, float dt2, float lap)
 {
     const float prod = (v2 * dt2) * lap;
-#if FDW_ABLATE == 1 || (FDW_ABL_BITS & 1)
+#if FDW_ABL_BITS & 1
     return (2.0f * p - pp) + prod;
 #endif
     const double d = 2.0 * (double)p - (double)pp + (double)prod;
@@ -200,7 +178,7 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
 {
     using G = RingGeom<H, PF>;
     constexpr int NW = G::NW, R = G::R, LOOK = G::LOOK;
-#if FDW_ABLATE == 10
+#if FDW_ABL_BITS & 32
     const size_t pitch = 0;   // every row aliases row 0: loads become L1 hits -> pure issue/VALU time
 #else
     const size_t pitch = (size_t)a.pitch;
@@ -265,7 +243,7 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
     // ---- loaders: unconditional, clamped --------------------------------------------------------
     auto load_p = [&](int row) -> f4 { return f4_load(a.p + (size_t)min(max(row, 0), rowmax) * pitch, voff); };
     auto load_halo = [&](int row) -> f4 {
-#if FDW_ABLATE == 2 || (FDW_ABL_BITS & 2)
+#if FDW_ABL_BITS & 2
         return f4_zero();
 #endif
         return f4_load(a.p + (size_t)row * pitch, hoff);
@@ -375,7 +353,7 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
 #pragma unroll
                 for (int e = 0; e < 4; ++e) imr.v[e] = qim[Q].v[e] + qps[Q].v[e] * res.v[e];
             }
-#if FDW_ABLATE == 4 || FDW_ABLATE == 10 || (FDW_ABL_BITS & 4)
+#if FDW_ABL_BITS & (4 | 32)
             if (res.v[0] == 123.456f)
 #endif
             if (!partial) {
@@ -729,14 +707,21 @@ __global__ __launch_bounds__(256) void fdw_taper_finalize_kernel(float* f, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// wave-shift self test: out[lane] = {wave_shr1(src, old), wave_shl1(src, old)} -- lets the host
-// verify on the actual device that DPP wave shifts behave as the step kernel assumes.
+// device self test of the two hardware behaviours the kernels rely on:
+//   out[0..63]    = __shfl_up(src, 1)     (lane 0 keeps its own value)
+//   out[64..127]  = __shfl_down(src, 1)   (lane 63 keeps its own value)
+//   out[128..383] = a 64 x float4 row written with the range-predicated buffer store: lanes 2..61 store at
+//                   their own offset, the others at 0xFFFFFFF0 and must be dropped by the descriptor check
 // ------------------------------------------------------------------------------------------------
-__global__ void fdw_dpp_selftest_kernel(const float* src, const float* old, float* out)
+__global__ void fdw_selftest_kernel(const float* src, float* out)
 {
     const int t = threadIdx.x;
-    out[t] = wave_shr1(src[t], old[t]);
-    out[64 + t] = wave_shl1(src[t], old[t]);
+    out[t] = __shfl_up(src[t], 1, 64);
+    out[64 + t] = __shfl_down(src[t], 1, 64);
+    f4 v;
+    v.v[0] = v.v[1] = v.v[2] = v.v[3] = src[t];
+    const unsigned off = (t >= 2 && t <= 61) ? (unsigned)t * 16u : 0xFFFFFFF0u;
+    f4_store_rsrc(out + 128, 64u * 16u, off, v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -804,9 +789,9 @@ hipError_t launch_taper_finalize(float* f, const float* taperz, const float* txf
     return hipGetLastError();
 }
 
-hipError_t launch_dpp_selftest(const float* src, const float* old, float* out, hipStream_t s)
+hipError_t launch_selftest(const float* src, float* out, hipStream_t s)
 {
-    hipLaunchKernelGGL(fdw_dpp_selftest_kernel, dim3(1), dim3(64), 0, s, src, old, out);
+    hipLaunchKernelGGL(fdw_selftest_kernel, dim3(1), dim3(64), 0, s, src, out);
     return hipGetLastError();
 }
 

@@ -21,7 +21,7 @@ def mko(d):
                     compat=d.get("compat", True))
 
 
-def test_dpp_wave_shift_selftest():
+def test_device_selftest():
     F.FDWave(8, 64, 64).selftest()
 
 
@@ -429,3 +429,54 @@ def test_two_step_kernel_vs_oracle_bit_exact(case):
                 tag = f"{init} nsteps={nsteps} xchunk={xchunk}"
                 assert_bit_equal(bufs[ipp][:, :nze].cpu().numpy(), oPP, "PP " + tag)
                 assert_bit_equal(bufs[ip][:, :nze].cpu().numpy(), oP, "P " + tag)
+
+
+EDGE_DECKS = [
+    # nxe, nze, nxb, nzb, nt, order, compat, note
+    (70, 90, 0, 0, 12, 8, True),          # no absorbing border at all (ztap = 0, no x taper)
+    (70, 90, 0, 11, 12, 8, True),         # z taper only
+    (70, 90, 9, 0, 12, 8, False),         # x border without a damped strip
+    (83, 67, 13, 9, 12, 2, True),         # order 2 with truncated extents: kernel_lap's grid stops short of the interior (h + xlim)
+    (83, 67, 13, 9, 10, 4, True),
+    (90, 700, 12, 300, 10, 8, True),      # damped strip wider than a 256-column lane strip (two strips take the taper path)
+    (64, 256, 8, 16, 10, 8, True),        # exactly one full strip
+    (64, 480, 8, 16, 10, 8, False),       # two-step tiles: exactly 2 x 60 cells
+    (64, 512, 8, 16, 10, 8, True),
+    (41, 41, 4, 4, 9, 8, True),           # barely larger than the stencil; taper narrower than 8 (ztap = 0 in compat)
+    (60, 70, 10, 10, 8, 32, False),       # maximum order (generic kernel)
+]
+
+
+@pytest.mark.parametrize("case", EDGE_DECKS, ids=lambda c: "x".join(map(str, c)))
+def test_edge_decks_forward_back_and_two_step(case):
+    nxe, nze, nxb, nzb, nt, order, compat = case
+    d = make_deck(nxe, nze, nxb, nzb, nt, seed=nxe * 7 + nze, order=order, compat=compat, fac=0.6)
+    d["sx"], d["sz"], d["gz"] = nxb + 3, max(nzb, order // 2) + 1, max(nzb, order // 2) + 2
+    nx, nz = nxe - 2 * nxb, nze - 2 * nzb
+    srce = O.ricker_wavelet(nt, d["dt"], 30.0)
+    p0, pp0 = random_fields(d, seed=3, amp=0.1)
+    ctx, orc = mk(d), mko(d)
+    for two_step in (-1, 1) if order == 8 else (0,):
+        ctx.set_tuning(two_step=two_step)
+        for p, pp, n in ((None, None, nt), (p0, pp0, nt), (p0, pp0, 3)):
+            P, PP = ctx.forward(d["v2"], d["sx"], d["sz"], srce, p, pp, nsteps=n)
+            oP, oPP = orc.forward(d["v2"], d["sx"], d["sz"], srce, p, pp, nsteps=n)
+            assert_bit_equal(P, oP, f"P two_step={two_step} n={n}")
+            assert_bit_equal(PP, oPP, f"PP two_step={two_step} n={n}")
+    d_obs = np.random.default_rng(1).standard_normal((nx, nt)).astype(np.float32)
+    oP, oPP = orc.forward(d["v2"], d["sx"], d["sz"], srce)
+    assert_bit_equal(ctx.shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs), orc.back(d["v2"], oP, oPP, d_obs, d["gz"]), "image")
+
+
+def test_source_position_sweep_two_step():
+    """The injected sample must land in every wave that recomputes the point (tile overlap of the two-step kernel)."""
+    d = make_deck(130, 560, 10, 12, 6, seed=9, compat=False)
+    srce = np.array([1.0, -2.0, 3.0, 0.5, -1.5, 2.5], np.float32)
+    ctx, orc = mk(d), mko(d)
+    ctx.set_tuning(two_step=1, xchunk=12)
+    for sx in (10, 11, 12, 13, 21, 22, 23, 34, 64, 119):
+        for sz in (12, 239, 240, 241, 247, 248, 479, 480, 481, 547):
+            P, PP = ctx.forward(d["v2"], sx, sz, srce)
+            oP, oPP = orc.forward(d["v2"], sx, sz, srce)
+            assert_bit_equal(PP, oPP, f"PP source at ({sx},{sz})")
+            assert_bit_equal(P, oP, f"P source at ({sx},{sz})")
