@@ -118,7 +118,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if world == 1:
+    if world == 1 and not os.environ.get("FDW_FORCE_SLAB_DRIVER"):
         # One GPU: the library's forward loop over four rotating buffers (fdw_dev_steps2): pairs of time steps go
         # through the two-step kernel (temporal blocking) where it pays, everything enqueued by ONE library call.
         skew = int(os.environ.get("FDW_ALLOC_SKEW", "0"))     # tuning experiments only: bytes of padding between the field buffers
