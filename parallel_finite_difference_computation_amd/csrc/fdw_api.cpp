@@ -65,7 +65,7 @@ struct fdw_ctx {
     float *d_taperz = nullptr, *d_txfac = nullptr, *d_gcx = nullptr, *d_gcz = nullptr;
     hipStream_t stream = nullptr;
     // lazily allocated work buffers of the host-array API
-    float* fld[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* fld[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float *d_v2 = nullptr, *d_img = nullptr, *d_srce = nullptr, *d_dobs = nullptr;
     size_t srce_cap = 0, dobs_cap = 0;
     // tuning
@@ -265,7 +265,7 @@ extern "C" void fdw_destroy(fdw_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     float* bufs[] = {c->d_taperz, c->d_txfac, c->d_gcx, c->d_gcz, c->fld[0], c->fld[1], c->fld[2], c->fld[3],
-                     c->d_v2, c->d_img, c->d_srce, c->d_dobs};
+                     c->fld[4], c->fld[5], c->fld[6], c->fld[7], c->d_v2, c->d_img, c->d_srce, c->d_dobs};
     for (float* b : bufs)
         if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -395,8 +395,27 @@ extern "C" int fdw_dev_steps(fdw_ctx* c, float* d_p, float* d_pp, const float* d
 }
 
 // ---- two time steps per pass (temporal blocking) --------------------------------------------------
-static int step2_impl(fdw_ctx* c, const float* d_p, const float* d_pp, const float* d_v2, float* d_out1, float* d_out2, int pp_twice,
-                      const float* d_srce_it, int sx_global, int sz, hipStream_t s)
+// The two-step kernel wins where a launch is bandwidth bound (>= 8192^2: +18 %, 16384^2: +47 %); on small decks a
+// launch is a latency chain and the longer march loses (new_mod: 12 vs 5 us/step), so the one-step kernel stays.
+static bool two_step_pays(const fdw_ctx* c)
+{
+    if (c->h != kMaxFastHalfOrder || c->use_generic || c->tb < 0) return false;
+    if (c->tb > 0) return true;
+    return (long)c->upd_x1 * ((c->pitch / 4 + 59) / 60) >= 200000;
+}
+
+struct Step2Extra {          // what the receiver / imaging variant needs on top of the forward one
+    const float* inj2 = nullptr;
+    const float* psrc_a = nullptr;
+    const float* psrc_b = nullptr;
+    float* img = nullptr;
+};
+
+// mode FWD: d_inj -> {srce[it], srce[it+1]}, inj_x_global / inj_z = source position (inj_x_global < 0: none)
+// mode PLAIN: no taper, no injection
+// mode RECV: d_inj / ex.inj2 -> receiver samples of iterations it / it+1 (nx each), inj_z = gz, imaging with ex.psrc_a/b
+static int step2_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp, const float* d_v2, float* d_out1, float* d_out2, int pp_twice,
+                      const float* d_inj, int inj_x_global, int inj_z, const Step2Extra& ex, hipStream_t s)
 {
     if (c->h != kMaxFastHalfOrder) return fail(FDW_EINVAL, "step2: the two-step kernel is built for order 8 only");
     if (!d_p || !d_pp || !d_v2 || !d_out1 || !d_out2) return fail(FDW_EINVAL, "step2: NULL buffer");
@@ -404,19 +423,29 @@ static int step2_impl(fdw_ctx* c, const float* d_p, const float* d_pp, const flo
         return fail(FDW_EINVAL, "step2: outputs must not alias the inputs (tiles re-read each other's input rows)");
     Step2Args a{};
     a.p = d_p; a.pp = d_pp; a.v2 = d_v2; a.out1 = d_out1; a.out2 = d_out2;
-    a.taperz = c->d_taperz; a.txfac = c->d_txfac; a.inj = d_srce_it;
+    a.taperz = c->d_taperz; a.txfac = c->d_txfac; a.inj = d_inj; a.inj2 = ex.inj2;
+    a.psrc_a = ex.psrc_a; a.psrc_b = ex.psrc_b; a.img = ex.img;
     a.pitch = c->pitch; a.nxl = c->nxl;
     a.r0 = 0; a.r1 = c->upd_x1;
     a.lap_x0 = c->lap_x0; a.lap_x1 = c->lap_x1; a.lap_z0 = c->lap_z0; a.lap_z1 = c->lap_z1;
     a.upd_x1 = c->upd_x1; a.upd_z1 = c->upd_z1;
     a.ztap = c->ztap; a.tz_x1 = c->tz_x1; a.xt_lo = c->xt_lo; a.xt_hi = c->xt_hi;
     a.pp_twice = pp_twice ? 1 : 0;
-    a.inj_x = -1000000; a.inj_z = sz;
-    if (d_srce_it && sx_global >= 0) {
-        if (sz < 0 || sz >= c->prm.nze || sx_global >= c->prm.nxe) return fail(FDW_EINVAL, "step2: source (%d,%d) outside the grid", sx_global, sz);
-        a.inj_x = sx_global - c->slab.x_off;
+    a.inj_x = -1000000; a.inj_z = inj_z; a.inj_n = 0;
+    if (mode == FDW_MODE_FWD && d_inj && inj_x_global >= 0) {
+        if (inj_z < 0 || inj_z >= c->prm.nze || inj_x_global >= c->prm.nxe) return fail(FDW_EINVAL, "step2: source (%d,%d) outside the grid", inj_x_global, inj_z);
+        a.inj_x = inj_x_global - c->slab.x_off;
         if (a.inj_x >= c->upd_x1 && a.inj_x < c->nxl)
-            return fail(FDW_EINVAL, "step2: source row %d lies in rows the reference never time-steps (>= %d)", sx_global, c->xlim);
+            return fail(FDW_EINVAL, "step2: source row %d lies in rows the reference never time-steps (>= %d)", inj_x_global, c->xlim);
+    } else if (mode == FDW_MODE_RECV) {
+        if (!d_inj || !ex.inj2 || !ex.psrc_a || !ex.psrc_b || !ex.img) return fail(FDW_EINVAL, "step2: RECV needs both sample rows, both source fields and the image");
+        if (inj_z < 0 || inj_z >= c->prm.nze) return fail(FDW_EINVAL, "step2: receiver depth %d outside the grid", inj_z);
+        const int g0 = c->prm.nxb, g1 = c->prm.nxb + std::min(c->nx, c->xlim);       // receivers on interior columns (R:126-129)
+        const int l0 = std::max(g0 - c->slab.x_off, 0), l1 = std::min(g1 - c->slab.x_off, c->nxl);
+        a.inj_x = l0;
+        a.inj_n = std::max(0, l1 - l0);
+        a.inj = d_inj + (l0 + c->slab.x_off - g0);
+        a.inj2 = ex.inj2 + (l0 + c->slab.x_off - g0);
     }
     a.dt2 = c->dt2;
     for (int io = 0; io <= 2 * kMaxFastHalfOrder; io++) { a.cx[io] = c->cx[io]; a.cz[io] = c->cz[io]; }
@@ -433,7 +462,7 @@ static int step2_impl(fdw_ctx* c, const float* d_p, const float* d_pp, const flo
     const int chunks = (rows + xchunk - 1) / xchunk;
     a.nblk = a.nzblk * chunks;
     a.nper = (a.nblk + 7) / 8;
-    hipError_t e = launch_step2(a, c->h, 1, s);
+    hipError_t e = launch_step2(a, c->h, mode, s);
     if (e != hipSuccess) return fail(FDW_EHIP, "step2 launch failed: %s", hipGetErrorString(e));
     // rows the reference never time-steps (compat, nxe not a multiple of 8): both fields are static there and
     // swap roles every step, so after two steps out1 carries pp's rows and out2 p's rows
@@ -445,22 +474,13 @@ static int step2_impl(fdw_ctx* c, const float* d_p, const float* d_pp, const flo
     return FDW_OK;
 }
 
-// The two-step kernel wins where a launch is bandwidth bound (>= 8192^2: +12 %, 16384^2: +42 %); on small decks a
-// launch is a latency chain and the longer march loses (new_mod: 12 vs 5 us/step), so the one-step kernel stays.
-static bool two_step_pays(const fdw_ctx* c)
-{
-    if (c->h != kMaxFastHalfOrder || c->use_generic || c->tb < 0) return false;
-    if (c->tb > 0) return true;
-    return (long)c->upd_x1 * ((c->pitch / 4 + 59) / 60) >= 200000;
-}
-
 extern "C" int fdw_two_step_active(const fdw_ctx* c) { return c && two_step_pays(c) ? 1 : 0; }
 
 extern "C" int fdw_dev_step2(fdw_ctx* c, const float* d_p, const float* d_pp, const float* d_v2, float* d_out1, float* d_out2, int pp_twice,
                              const float* d_srce_it, int sx, int sz, void* stream)
 {
     if (!c) return fail(FDW_EINVAL, "ctx is NULL");
-    return step2_impl(c, d_p, d_pp, d_v2, d_out1, d_out2, pp_twice, d_srce_it, sx, sz, pick_stream(c, stream));
+    return step2_impl(c, FDW_MODE_FWD, d_p, d_pp, d_v2, d_out1, d_out2, pp_twice, d_srce_it, d_srce_it ? sx : -1, sz, Step2Extra{}, pick_stream(c, stream));
 }
 
 // nsteps reference iterations (R:259-267) over four rotating buffers: pairs of steps through the two-step
@@ -480,7 +500,8 @@ extern "C" int fdw_dev_steps2(fdw_ctx* c, float* const* buf, const float* d_v2, 
             for (int i = 0, n = 0; i < 4; i++)
                 if (i != *ip && i != *ipp) { (n++ == 0 ? o1 : o2) = i; }
             // after the swap the kernel's p is the old d_pp (newest field), its pp the old d_p
-            int rc = step2_impl(c, buf[*ipp], buf[*ip], d_v2, buf[o1], buf[o2], twice, d_srce ? d_srce + it0 + k : nullptr, d_srce ? sx : -1, sz, s);
+            int rc = step2_impl(c, FDW_MODE_FWD, buf[*ipp], buf[*ip], d_v2, buf[o1], buf[o2], twice, d_srce ? d_srce + it0 + k : nullptr,
+                                d_srce ? sx : -1, sz, Step2Extra{}, s);
             if (rc) return rc;
             *ip = o1; *ipp = o2;   // d_p = u^{n+1}, d_pp = u^{n+2}
             k += 2;
@@ -655,49 +676,66 @@ static int image_to_host(fdw_ctx* c, float* imloc)
     return FDW_OK;
 }
 
-// fd_back's loop R:302-339.  The two snapshots are either host arrays (uploaded into d_pp at it=0,1
-// exactly like R:304-314) or already on the device (dsnap0/dsnap1, used in place).
-static int back_loop(fdw_ctx* c, const float* hsnap0, const float* hsnap1, float* dsnap0, float* dsnap1, int gz, int nsteps)
+// fd_back's loop R:302-339 on device buffers.
+//   F_k  = source wavefield of iteration k:  F_0 = snap1 (u^nt), F_1 = snap0 (u^{nt-1}, R:304-314),
+//          F_k = leap-frog(F_{k-1}, F_{k-2}) for k >= 2 (no taper, no source, R:317-318)
+//   r^k  = receiver field: r^{k+1} = damped leap-frog(r^k, r^{k-1}) + d_obs[.][nt-1-k] on row gz (R:325-328)
+//   img += F_k * r^{k+1}  (R:329)
+// Iterations are taken in PAIRS through the two-step kernel where it pays (one pass reconstructs F_k, F_{k+1}; one
+// pass advances the receiver field twice and applies both imaging conditions), singly through the one-step kernels
+// otherwise.  src[0..3] / rcv[0..3]: rotating buffers; on entry src[0] = snap0, src[1] = snap1, the receivers are zero.
+static int back_loop(fdw_ctx* c, float* const src[4], float* const rcv[4], int gz, int nsteps)
 {
-    float *d_p, *d_pp, *d_pr = c->fld[2], *d_ppr = c->fld[3];
-    const bool resident = (dsnap0 != nullptr);
-    if (resident) {
-        d_p = nullptr; d_pp = nullptr;
-        // the forward pass rotates through all four buffers: the receiver pair takes the two that do not hold the snapshots
-        float* spare[2] = {nullptr, nullptr};
-        for (int i = 0, n = 0; i < 4 && n < 2; i++)
-            if (c->fld[i] != dsnap0 && c->fld[i] != dsnap1) spare[n++] = c->fld[i];
-        d_pr = spare[0]; d_ppr = spare[1];
-    } else {
-        d_p = c->fld[0]; d_pp = c->fld[1];
-        HIP_TRY(hipMemsetAsync(d_p, 0, field_elems(c) * sizeof(float), c->stream));
-        HIP_TRY(hipMemsetAsync(d_pp, 0, field_elems(c) * sizeof(float), c->stream));
-    }
-    HIP_TRY(hipMemsetAsync(d_pr, 0, field_elems(c) * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(d_ppr, 0, field_elems(c) * sizeof(float), c->stream));
     const int nt = c->prm.nt;
-    for (int it = 0; it < nsteps; it++) {
-        int rc;
-        if (resident) {
-            // it=0: source field = u^nt (dsnap1); it=1: u^{nt-1} (dsnap0); afterwards step backwards in time
-            if (it == 0) { d_p = dsnap1; d_pp = dsnap0; }
-            else if (it == 1) { d_p = dsnap0; d_pp = dsnap1; }
-            else {
-                if ((rc = step_impl(c, FDW_MODE_PLAIN, d_p, d_pp, c->d_v2, 0, c->nxl, 0, nullptr, -1, 0, nullptr, nullptr, c->stream))) return rc;
-                std::swap(d_p, d_pp);
-            }
-        } else {
-            if (it < 2) {
-                if ((rc = upload_rows(c, d_pp, it == 0 ? hsnap1 : hsnap0, c->stream))) return rc;
+    const size_t nxs = (size_t)c->nx;
+    auto samples = [&](int it) { return c->d_dobs + (size_t)(nt - 1 - it) * nxs; };
+    int f1 = 0, f0 = 1;          // indices into src of F_{k-1} (newer) and F_{k-2}: before iteration 2 these are snap0, snap1
+    int rn = 0, ro = 1;          // indices into rcv of r^k (d_pr) and r^{k-1} (d_ppr)
+    int rc;
+    int it = 0;
+    const bool pairs = two_step_pays(c);
+    while (it < nsteps) {
+        if (pairs && nsteps - it >= 2) {
+            const float *Fa, *Fb;   // source fields of iterations it, it+1
+            if (it == 0) {
+                Fa = src[1]; Fb = src[0];                      // u^nt, u^{nt-1}
             } else {
-                if ((rc = step_impl(c, FDW_MODE_PLAIN, d_p, d_pp, c->d_v2, 0, c->nxl, 0, nullptr, -1, 0, nullptr, nullptr, c->stream))) return rc;
+                int o1 = -1, o2 = -1;
+                for (int i = 0; i < 4; i++)
+                    if (i != f1 && i != f0) { (o1 < 0 ? o1 : o2) = i; }
+                if ((rc = step2_impl(c, FDW_MODE_PLAIN, src[f1], src[f0], c->d_v2, src[o1], src[o2], 0, nullptr, -1, 0, Step2Extra{}, c->stream))) return rc;
+                Fa = src[o1]; Fb = src[o2];
+                f0 = o1; f1 = o2;
             }
-            std::swap(d_p, d_pp);  // R:321-323
+            int q1 = -1, q2 = -1;
+            for (int i = 0; i < 4; i++)
+                if (i != rn && i != ro) { (q1 < 0 ? q1 : q2) = i; }
+            Step2Extra ex;
+            ex.inj2 = samples(it + 1); ex.psrc_a = Fa; ex.psrc_b = Fb; ex.img = c->d_img;
+            if ((rc = step2_impl(c, FDW_MODE_RECV, rcv[rn], rcv[ro], c->d_v2, rcv[q1], rcv[q2], it > 0, samples(it), -1, gz, ex, c->stream))) return rc;
+            ro = q1; rn = q2;
+            it += 2;
+        } else {
+            const float* F;
+            if (it == 0) F = src[1];
+            else if (it == 1) F = src[0];
+            else {
+                // one-step reconstruction in place: the new field overwrites F_{k-2}
+                if ((rc = step_impl(c, FDW_MODE_PLAIN, src[f1], src[f0], c->d_v2, 0, c->nxl, 0, nullptr, -1, 0, nullptr, nullptr, c->stream))) return rc;
+                std::swap(f1, f0);
+                F = src[f1];
+            }
+            if ((rc = step_impl(c, FDW_MODE_RECV, rcv[rn], rcv[ro], c->d_v2, 0, c->nxl, it > 0, samples(it), 0, gz, F, c->d_img, c->stream))) return rc;
+            std::swap(rn, ro);
+            it += 1;
         }
-        const float* samples = c->d_dobs + (size_t)(nt - 1 - it) * c->nx;
-        if ((rc = step_impl(c, FDW_MODE_RECV, d_pr, d_ppr, c->d_v2, 0, c->nxl, it > 0, samples, 0, gz, d_p, c->d_img, c->stream))) return rc;
-        std::swap(d_pr, d_ppr);  // R:331-333
     }
+    return FDW_OK;
+}
+
+static int zero_fields(fdw_ctx* c, float* const f[], int n)
+{
+    for (int i = 0; i < n; i++) HIP_TRY(hipMemsetAsync(f[i], 0, field_elems(c) * sizeof(float), c->stream));
     return FDW_OK;
 }
 
@@ -710,9 +748,14 @@ extern "C" int fdw_back(fdw_ctx* c, const float* v2, const float* snap0, const f
     if (c->nx <= 0 || c->nz <= 0) return fail(FDW_EINVAL, "no interior to image");
     HIP_TRY(hipSetDevice(c->device));
     int rc;
-    if ((rc = ensure_work_buffers(c, 4, true))) return rc;
+    if ((rc = ensure_work_buffers(c, 8, true))) return rc;
     if ((rc = upload_rows(c, c->d_v2, v2, c->stream)) || (rc = upload_gather(c, d_obs)) || (rc = image_to_device(c, imloc))) return rc;
-    if ((rc = back_loop(c, snap0, snap1, nullptr, nullptr, gz, nsteps))) return rc;
+    // the reference uploads the two snapshots into d_pp at it = 0 and 1 (R:304-314); having both on the device up front is the same
+    if ((rc = upload_rows(c, c->fld[0], snap0, c->stream)) || (rc = upload_rows(c, c->fld[1], snap1, c->stream))) return rc;
+    float* const src[4] = {c->fld[0], c->fld[1], c->fld[2], c->fld[3]};
+    float* const rcv[4] = {c->fld[4], c->fld[5], c->fld[6], c->fld[7]};
+    if ((rc = zero_fields(c, rcv, 2))) return rc;                   // R:513-514
+    if ((rc = back_loop(c, src, rcv, gz, nsteps))) return rc;
     if ((rc = image_to_host(c, imloc))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return FDW_OK;
@@ -727,7 +770,7 @@ extern "C" int fdw_shot(fdw_ctx* c, const float* v2, int sx, int sz, int gz, con
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     const int nt = c->prm.nt;
-    if ((rc = ensure_work_buffers(c, 4, true))) return rc;
+    if ((rc = ensure_work_buffers(c, 8, true))) return rc;
     int ip = 0, ipp = 1;
     HIP_TRY(hipMemsetAsync(c->fld[0], 0, field_elems(c) * sizeof(float), c->stream));    // R:496-497
     HIP_TRY(hipMemsetAsync(c->fld[1], 0, field_elems(c) * sizeof(float), c->stream));
@@ -738,7 +781,13 @@ extern "C" int fdw_shot(fdw_ctx* c, const float* v2, int sx, int sz, int gz, con
     float *d_p = c->fld[ip], *d_pp = c->fld[ipp];
     if (P && (rc = download_rows(c, P, d_p, c->stream))) return rc;
     if (PP && (rc = download_rows(c, PP, d_pp, c->stream))) return rc;
-    if ((rc = back_loop(c, nullptr, nullptr, d_p, d_pp, gz, nt))) return rc;
+    // the snapshots stay where the forward pass left them; the other two of the first four buffers are the spares
+    float* src[4] = {d_p, d_pp, nullptr, nullptr};
+    for (int i = 0, n = 2; i < 4; i++)
+        if (c->fld[i] != d_p && c->fld[i] != d_pp) src[n++] = c->fld[i];
+    float* const rcv[4] = {c->fld[4], c->fld[5], c->fld[6], c->fld[7]};
+    if ((rc = zero_fields(c, rcv, 2))) return rc;
+    if ((rc = back_loop(c, src, rcv, gz, nt))) return rc;
     if ((rc = image_to_host(c, imloc))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return FDW_OK;

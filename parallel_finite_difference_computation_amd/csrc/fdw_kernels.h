@@ -49,19 +49,23 @@ struct Step2Args {
     float* out2;           // u^{n+2}
     const float* taperz;
     const float* txfac;
-    const float* inj;      // two source samples: srce[it], srce[it+1]
+    const float* inj;      // FWD: two source samples srce[it], srce[it+1]; RECV: receiver samples of iteration it (step 1)
+    const float* inj2;     // RECV: receiver samples of iteration it+1 (step 2)
+    const float* psrc_a;   // RECV: source wavefield of iteration it   (imaged against u^{n+1})
+    const float* psrc_b;   // RECV: source wavefield of iteration it+1 (imaged against u^{n+2})
+    float* img;            // RECV: image accumulator on the extended grid (in place, owned cells only)
     int pitch, nxl;
     int r0, r1;            // rows whose u^{n+1}, u^{n+2} this launch produces
     int lap_x0, lap_x1, lap_z0, lap_z1;
     int upd_x1, upd_z1;
     int ztap, tz_x1, xt_lo, xt_hi;
     int pp_twice;
-    int inj_x, inj_z;
+    int inj_x, inj_z, inj_n;
     int xchunk, nstrip, nzblk, nblk, nper;
     float dt2;
     float cx[2 * kMaxFastHalfOrder + 1], cz[2 * kMaxFastHalfOrder + 1];
 };
-hipError_t launch_step2(const Step2Args& a, int half_order, int taper, hipStream_t s);
+hipError_t launch_step2(const Step2Args& a, int half_order, int mode, hipStream_t s);
 
 hipError_t launch_step_fast(const StepArgs& a, int half_order, int mode, int prefetch, hipStream_t s);
 hipError_t launch_step_generic(const StepArgs& a, int half_order, int mode, hipStream_t s);

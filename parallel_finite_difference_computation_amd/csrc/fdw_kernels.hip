@@ -444,7 +444,7 @@ __device__ __forceinline__ void f4_store_rsrc(float* row, unsigned row_bytes, un
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), rs, voff_bytes, 0, (FDW_NT & 2) ? 2 : 0);
 }
 
-template <int H, bool TAPER, int PF>
+template <int H, bool TAPER, int INJ, bool IMG, int PF>
 __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const int cs, const int xa, const int xe, f4* stash)
 {
     constexpr int NW = 2 * H + 1;
@@ -462,9 +462,13 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
     const bool wave_tap = TAPER && (cs * 4 < a.ztap);
     const bool xtap = wave_tap && ((xa - 2 * H < a.xt_lo) || (xe + 2 * H > a.xt_hi));
     const bool inj_cols = (a.inj_z >= cs * 4) && (a.inj_z < cs * 4 + 256);
-    const bool inj_here = inj_cols && (a.inj_x >= xa - H) && (a.inj_x < xe + H);
-    const float inj0 = inj_here ? sload(a.inj, 0) : 0.0f;     // srce[it]   -> u^{n+1}
-    const float inj1 = inj_here ? sload(a.inj, 1) : 0.0f;     // srce[it+1] -> u^{n+2}
+    // INJ == 1: point source at (inj_x, inj_z), samples inj[0] -> u^{n+1}, inj[1] -> u^{n+2}          (kernel_src, R:119-122)
+    // INJ == 2: receiver row z = inj_z, rows [inj_x, inj_x+inj_n): inj[row-inj_x] -> u^{n+1}, inj2[..] -> u^{n+2} (kernel_sism)
+    bool inj_here = false;
+    if (INJ == 1) inj_here = inj_cols && (a.inj_x >= xa - H) && (a.inj_x < xe + H);
+    if (INJ == 2) inj_here = inj_cols && (a.inj_x < xe + H) && (a.inj_x + a.inj_n > xa - H);
+    const float inj0 = (INJ == 1 && inj_here) ? sload(a.inj, 0) : 0.0f;
+    const float inj1 = (INJ == 1 && inj_here) ? sload(a.inj, 1) : 0.0f;
 
     bool mlap[4], mupd[4], znc[4], ihit[4];
     float tzc[4];
@@ -501,7 +505,7 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
     const int s0 = xa - H, b0 = xa - 2 * H;
     const int M = (xe - xa) + 2 * H;
     f4 ring1[R], ring2[R];
-    f4 qpp[PF], qv2[PF];
+    f4 qpp[PF], qv2[PF], qsa[PF], qsb[PF], qim[PF];
     static_for<R>([&](auto K) { constexpr int k = decltype(K)::value; ring2[k] = f4_zero(); });
     constexpr int NV = LOOK > PF ? LOOK : PF;
     static_for<2 * H>([&](auto K) {
@@ -516,6 +520,11 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
             constexpr int m = j + PF;
             qpp[m] = load_pw(a.pp, s0 + m);
             qv2[m] = load_pw(a.v2, s0 + m);
+            if constexpr (IMG) {
+                qsa[m] = load_pw(a.psrc_a, s0 + m - H);
+                qsb[m] = load_pw(a.psrc_b, s0 + m - H);
+                qim[m] = load_pw(a.img, s0 + m - H);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -566,10 +575,14 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
                 const float upd = leapfrog_pt(c1.v[e], ppt.v[e], qv2[Q].v[e], a.dt2, lap);
                 u1.v[e] = (rowupd1 && mupd[e]) ? upd : ppt.v[e];
             }
-            if (inj_here) {
-                if (s == a.inj_x) {
+            if constexpr (INJ != 0) {
+                if (inj_here) {
+                    const bool hit = (INJ == 1) ? (s == a.inj_x) : ((s >= a.inj_x) && (s < a.inj_x + a.inj_n));
+                    if (hit) {
+                        const float v = (INJ == 1) ? inj0 : sload(a.inj, s - a.inj_x);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) u1.v[e] = ihit[e] ? u1.v[e] + inj0 : u1.v[e];
+                        for (int e = 0; e < 4; ++e) u1.v[e] = ihit[e] ? u1.v[e] + v : u1.v[e];
+                    }
                 }
             }
             f4_store_rsrc(a.out1 + (size_t)min(max(s, 0), rowmax) * pitch, row_bytes, soff1, u1);
@@ -601,18 +614,39 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
                     const float upd = leapfrog_pt(c2.v[e], pp2.v[e], v2r.v[e], a.dt2, lap);
                     u2.v[e] = mupd[e] ? upd : pp2.v[e];
                 }
-                if (inj_here) {
-                    if (r == a.inj_x) {
+                if constexpr (INJ != 0) {
+                    if (inj_here) {
+                        const bool hit = (INJ == 1) ? (r == a.inj_x) : ((r >= a.inj_x) && (r < a.inj_x + a.inj_n));
+                        if (hit) {
+                            const float v = (INJ == 1) ? inj1 : sload(a.inj2, r - a.inj_x);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) u2.v[e] = ihit[e] ? u2.v[e] + inj1 : u2.v[e];
+                            for (int e = 0; e < 4; ++e) u2.v[e] = ihit[e] ? u2.v[e] + v : u2.v[e];
+                        }
                     }
                 }
                 f4_store_rsrc(a.out2 + (size_t)min(max(r, 0), rowmax) * pitch, row_bytes, soff2, u2);
+                if constexpr (IMG) {
+                    // imaging condition of BOTH iterations at row r (kernel_img, R:133-144):  img += psrc_a * u^{n+1}, then
+                    // img += psrc_b * u^{n+2}.  u^{n+1}(r) is ring2's centre row; where the image is extracted (interior) no
+                    // damping applies, so the damped copy held there is the raw field.  Only owned cells are stored.
+                    f4 im = qim[Q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        im.v[e] = im.v[e] + qsa[Q].v[e] * c2.v[e];
+                        im.v[e] = im.v[e] + qsb[Q].v[e] * u2.v[e];
+                    }
+                    f4_store_rsrc(a.img + (size_t)min(max(r, 0), rowmax) * pitch, row_bytes, soff2, im);
+                }
             }
             // ================= look-ahead loads into the slots this step freed =====================
             ring1[U] = load_p(b0 + m + R);
             qpp[Q] = load_pw(a.pp, s + PF);
             qv2[Q] = load_pw(a.v2, s + PF);
+            if constexpr (IMG) {
+                qsa[Q] = load_pw(a.psrc_a, r + PF);
+                qsb[Q] = load_pw(a.psrc_b, r + PF);
+                qim[Q] = load_pw(a.img, r + PF);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -621,7 +655,7 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
         static_for<R>([&](auto UU) { row_step(mb, UU); });
 }
 
-template <int H, bool TAPER, int PF>
+template <int H, bool TAPER, int INJ, bool IMG, int PF>
 __global__ __launch_bounds__(256) void fdw_step2_kernel(const Step2Args a)
 {
     const int lane = threadIdx.x & 63;
@@ -638,7 +672,7 @@ __global__ __launch_bounds__(256) void fdw_step2_kernel(const Step2Args a)
     if (xa >= xe) return;
     // per-wave LDS slab: 8 rows x 64 lanes x 16 B for the v2 rows waiting between step 1 (row s) and step 2 (row s-H)
     __shared__ f4 v2_stash[4][8 * 64];
-    march2<H, TAPER, PF>(a, lane, strip * 60 - 2, xa, xe, v2_stash[w]);
+    march2<H, TAPER, INJ, IMG, PF>(a, lane, strip * 60 - 2, xa, xe, v2_stash[w]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -759,13 +793,17 @@ hipError_t launch_step_fast(const StepArgs& a, int h, int mode, int pf, hipStrea
     }
 }
 
-hipError_t launch_step2(const Step2Args& a, int h, int taper, hipStream_t s)
+hipError_t launch_step2(const Step2Args& a, int h, int mode, hipStream_t s)
 {
     if (a.nper <= 0) return hipSuccess;
     if (h != 4) return hipErrorInvalidValue;
     const dim3 grid(8 * a.nper), block(256);
-    if (taper) hipLaunchKernelGGL((fdw_step2_kernel<4, true, 2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((fdw_step2_kernel<4, false, 2>), grid, block, 0, s, a);
+    switch (mode) {
+    case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_step2_kernel<4, true, 1, false, 2>), grid, block, 0, s, a); break;
+    case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_step2_kernel<4, false, 0, false, 2>), grid, block, 0, s, a); break;
+    case FDW_MODE_RECV:  hipLaunchKernelGGL((fdw_step2_kernel<4, true, 2, true, 2>), grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

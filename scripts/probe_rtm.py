@@ -40,7 +40,22 @@ def big(n, nt):
     print(f"n={n}: forward step + backward iteration = {per*1e6:.1f} us  -> {n*n/per/1e9:.1f} Gpt/s per (fwd+bwd) pair, "
           f"{n*n*(16+44)/per/1e12:.2f} TB/s algorithmic (16 + 44 B/pt)", flush=True)
 
+def shot_time(n, nt, two_step):
+    nb = 64
+    ctx = F.FDWave(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 1e-3, compat=False)
+    ctx.set_tuning(two_step=two_step)
+    rng = np.random.default_rng(0)
+    v2 = np.full((n, n), 2500.0 ** 2, np.float32)
+    d_obs = rng.standard_normal((n - 2 * nb, nt)).astype(np.float32)
+    srce = F.ricker_wavelet(nt, 1e-3, 20.0)
+    ctx.shot(v2, n // 2, nb + 2, nb + 2, srce, d_obs)
+    t0 = time.perf_counter(); ctx.shot(v2, n // 2, nb + 2, nb + 2, srce, d_obs); return time.perf_counter() - t0
+
 if __name__ == "__main__":
     new_mod_program()
-    for n in (4096, 8192):
-        big(n, 60)
+    for n in (8192,):
+        for two in (-1, 1):
+            a, b = shot_time(n, 40, two), shot_time(n, 120, two)
+            per = (b - a) / 80
+            print(f"n={n} two_step={two}: forward step + backward iteration = {per*1e6:.1f} us -> {n*n/per/1e9:.1f} Gpt/s per pair of passes "
+                  f"({n*n*60/per/1e12:.2f} TB/s of 16+44 B/pt)", flush=True)

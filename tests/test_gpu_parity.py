@@ -168,6 +168,10 @@ def test_host_api_with_forced_two_step_kernel(case):
     assert_bit_equal(P, oP, "shot P two-step")
     assert_bit_equal(PP, oPP, "shot PP two-step")
     assert_bit_equal(img, oimg, "shot image two-step")
+    im0 = np.random.default_rng(6).standard_normal((nx, nz)).astype(np.float32)
+    for n in (nt, 1, 2, 3, 4, 7):      # paired backward iterations with odd / even counts, image accumulated onto a non-zero one
+        assert_bit_equal(ctx.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n),
+                         orc.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n), f"back two-step nsteps={n}")
     ctx.set_tuning(two_step=-1)
     assert_bit_equal(ctx.shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs), oimg, "shot image one-step")
 
