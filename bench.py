@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--ksteps", type=int, default=0, help="time steps per halo exchange (N > 1); 0 = auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU rehearsals)")
+    ap.add_argument("--check", action="store_true", help="N > 1: compare the decomposed result with a single-domain run on rank 0 (small sizes)")
     ap.add_argument("--init", choices=["noise", "rest"], default="noise",
                     help="initial wavefield: seeded noise (default; every cache line carries real data) or at rest (zeros + source)")
     args = ap.parse_args()
@@ -86,12 +88,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (the product has no CPU path)")
+    if args.backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)     # rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     n, K, W = args.size, args.steps, args.warmup
     nt = K + W
@@ -190,6 +197,32 @@ def main():
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
         finite = bool(f.item() > 0.5)
 
+    if world > 1 and args.check:
+        own = newest[:, :n].contiguous()
+        parts = [torch.empty(((b1 - b0), n), device=dev) for (b0, b1) in __import__("parallel_finite_difference_computation_amd.decomp", fromlist=["slab_bounds"]).slab_bounds(n, world)] if rank == 0 else None
+        if rank == 0:
+            parts[0].copy_(own)
+            for r in range(1, world):
+                dist.recv(parts[r], src=r)
+            full = torch.cat(parts)
+            ref_ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank)
+            ref_ctx.set_tuning(two_step=-1)
+            rb = [torch.zeros((n, ref_ctx.pitch), device=dev) for _ in range(4)]
+            if args.init == "noise":
+                g = torch.Generator(device=dev)
+                for f_, seed in ((rb[0], 0x5EED0001), (rb[1], 0x5EED0002)):
+                    g.manual_seed(seed)
+                    f_[:, :n] = (1e-3 * torch.randn((n, 64), device=dev, generator=g)).repeat(1, n // 64)
+            rv2 = torch.zeros((n, ref_ctx.pitch), device=dev)
+            rv2[:, :n] = synthetic_velocity_rows(n, 0, n, dev)
+            ip, ipp = ref_ctx.dev_steps2([b_.data_ptr() for b_ in rb], rv2.data_ptr(), srce.data_ptr(), sx, sz, 0, W + K, False, 0, 1, stream=None)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(full, rb[ipp][:, :n]))
+            print(f"[check] decomposed ({world} slabs) == single domain, bitwise: {same}", file=sys.stderr, flush=True)
+            if not same:
+                sys.exit("bench --check: decomposed result differs from the single-domain result")
+        else:
+            dist.send(own, dst=0)
     if rank == 0:
         gpts = n * n * K / wall / 1e9
         # dominant kernel: the fused step.  At N = 1 one launch updates the whole grid; its average

@@ -141,9 +141,16 @@ class SlabForward:
         if self.cuda:
             if wait_compute:
                 self.comm.wait_stream(self.compute)
+            stream_aware = dist.get_backend(self.group) == "nccl"
+            if not stream_aware:
+                # rehearsal backends (gloo stages CUDA tensors through host copies on threads/streams of its own):
+                # fence the whole device on both sides so that only the exchange LOGIC is exercised
+                torch.cuda.synchronize()
             with torch.cuda.stream(self.comm):
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
+            if not stream_aware:
+                torch.cuda.synchronize()
         else:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()

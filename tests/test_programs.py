@@ -211,3 +211,27 @@ def test_reference_signature_compat_library():
     L.fd_back(8, rows(z), rows(z), rows(z), rows(z), rows(v2), nze, nxe, nt, 0, nzb + 1, nzb + 2, snaps_pp, rows(imloc), dobs_rows)
     assert_bit_equal(imloc, orc.back(v2, oP, oPP, d_obs[0], nzb + 2), "compat fd_back imloc")
     L.fd_free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,opts", [(2, ["--ksteps", "4"]), (3, ["--ksteps", "0", "--steps", "25"])])
+def test_multi_process_bench_rehearsal_on_one_gpu(ranks, opts, tmp_path):
+    """bench.py's N > 1 path end to end: torch.distributed.run, one process per slab, real HIP kernels, overlapped deep-halo
+    exchange -- with the gloo backend so that all ranks can share this box's single GPU (RCCL refuses duplicate devices).
+    --check gathers the slabs and compares them bitwise with a single-domain run."""
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--size", "1024",
+           "--steps", "24", "--warmup", "6", "--check", "--no-cpu-baseline"] + opts
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert f"decomposed ({ranks} slabs) == single domain, bitwise: True" in r.stderr
+    import json
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == ranks and out["scaling"] == "strong" and out["result_finite_nonzero"] and out["value"] > 0
