@@ -455,9 +455,11 @@ static int step2_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
     const int rows = a.r1 - a.r0;
     if (rows <= 0) return FDW_OK;
     // whole ring turns only (the march is branch-free, a partial turn still costs a full one): xchunk + 2H = 10k.
-    // Measured (scripts/probe_tb.py, noise-filled fields; +-5 % between boxes/runs): 16384^2 500 Gpt/s at 72,
-    // 8192^2 430-450 at 22 (42 is as good on some runs, 7 % worse on others), 4096^2 353 at 22.
-    int xchunk = c->xchunk2 > 0 ? c->xchunk2 : ((long)rows * a.nstrip >= 1000000 ? 72 : ((long)rows * a.nstrip >= 16384 ? 22 : 2));
+    // Measured (scripts/probe_tb.py / probe_slabsize.py, noise-filled fields, same-box A/B; +-5 % between boxes): 16384^2 449 Gpt/s
+    // at 42 (443 at 22, 444 at 72); 8192^2 442 at 32 (435 at 22, 408 at 42); 4128x8192 416-423 at 32; 2080x8192 375 at 32;
+    // 1056x8192 301 at 22 (267 at 32: too few waves).
+    const long strip_rows = (long)rows * a.nstrip;
+    int xchunk = c->xchunk2 > 0 ? c->xchunk2 : (strip_rows >= 1000000 ? 42 : (strip_rows >= 70000 ? 32 : (strip_rows >= 16384 ? 22 : 2)));
     a.xchunk = xchunk;
     const int chunks = (rows + xchunk - 1) / xchunk;
     a.nblk = a.nzblk * chunks;

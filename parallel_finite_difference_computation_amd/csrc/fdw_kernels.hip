@@ -128,6 +128,12 @@ __device__ __forceinline__ float laplacian_pt(const float* W, int e, const float
     }
     return acmz + acmx;
 }
+// the update once prod = (v2*dt2)*lap is formed (fp32, as the reference's float expression does; R:89)
+__device__ __forceinline__ float leapfrog_prod(float p, float pp, float prod)
+{
+    const double d = 2.0 * (double)p - (double)pp + (double)prod;
+    return (float)d;
+}
 __device__ __forceinline__ float leapfrog_pt(float p, float pp, float v2, float dt2, float lap)
 {
     const float prod = (v2 * dt2) * lap;
@@ -137,6 +143,73 @@ __device__ __forceinline__ float leapfrog_pt(float p, float pp, float v2, float 
     const double d = 2.0 * (double)p - (double)pp + (double)prod;
     return (float)d;
 }
+
+// ---- packed fp32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE fp32 operations per lane and instruction) --------------
+// The two-step kernel is VALU-issue bound (SQ counters: ~48 VALU instructions per point and step, 85 % VALU busy at
+// 8192^2), so the Laplacian of a lane's four cells is formed as two PAIRS.  Each product and each sum is still an
+// individually rounded fp32 operation in the reference's order -- bit-identical to laplacian_pt.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Window of 12 consecutive z values as aligned pairs: E[k] = (W[2k], W[2k+1]), O[k] = (W[2k+1], W[2k+2]).
+struct ZPairs {
+    v2f E[6], O[5];
+};
+__device__ __forceinline__ ZPairs zpairs(const f4& left, const f4& c, const f4& right)
+{
+    ZPairs z;
+    z.E[0] = v2f{left.v[0], left.v[1]};   z.E[1] = v2f{left.v[2], left.v[3]};
+    z.E[2] = v2f{c.v[0], c.v[1]};         z.E[3] = v2f{c.v[2], c.v[3]};
+    z.E[4] = v2f{right.v[0], right.v[1]}; z.E[5] = v2f{right.v[2], right.v[3]};
+    z.O[0] = v2f{left.v[1], left.v[2]};   z.O[1] = v2f{left.v[3], c.v[0]};
+    z.O[2] = v2f{c.v[1], c.v[2]};         z.O[3] = v2f{c.v[3], right.v[0]};
+    z.O[4] = v2f{right.v[1], right.v[2]};
+    return z;
+}
+// pair * weight, the weight taken from the low (SEL 0) or high (SEL 1) half of an SGPR pair for BOTH lanes (VOP3P op_sel):
+// written as asm because hipcc materialises a splat (c, c) SGPR pair per weight otherwise and then spills SGPRs.
+template <int SEL>
+__device__ __forceinline__ v2f pk_mul_sel(v2f w, v2f cpair)
+{
+    v2f r;
+    if constexpr (SEL == 0)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(w), "s"(cpair));
+    else
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(w), "s"(cpair));
+    return r;
+}
+// The weights are symmetric (fdw_host.c), so H+1 distinct values per direction travel as (H+2)/2 SGPR pairs.
+template <int H>
+struct CoefPairs {
+    v2f z[(H + 2) / 2], x[(H + 2) / 2];
+};
+template <int H>
+__device__ __forceinline__ CoefPairs<H> coef_pairs(const float* cx, const float* cz)
+{
+    CoefPairs<H> c;
+    static_for<(H + 2) / 2>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        constexpr int k1 = (2 * k + 1 <= H) ? 2 * k + 1 : H;
+        c.z[k] = v2f{cz[2 * k], cz[k1]};
+        c.x[k] = v2f{cx[2 * k], cx[k1]};
+    });
+    return c;
+}
+// Laplacian of cells (2P, 2P+1) of the lane: same accumulation order as laplacian_pt (R:66-72).
+template <int H, int P, class Col>
+__device__ __forceinline__ v2f laplacian_pair(const ZPairs& z, Col&& col, const CoefPairs<H>& c)
+{
+    v2f acmz = {0.0f, 0.0f}, acmx = {0.0f, 0.0f};
+    static_for<2 * H + 1>([&](auto IO) {
+        constexpr int io = decltype(IO)::value;
+        constexpr int k = 4 + 2 * P - H + io;                       // W index of the pair's first cell for this tap
+        constexpr int ic = io <= H ? io : 2 * H - io;
+        const v2f w = (k & 1) ? z.O[k >> 1] : z.E[k >> 1];
+        acmz = acmz + pk_mul_sel<ic & 1>(w, c.z[ic >> 1]);
+        acmx = acmx + pk_mul_sel<ic & 1>(col(IO), c.x[ic >> 1]);
+    });
+    return acmz + acmx;
+}
+__device__ __forceinline__ v2f f4_pair(const f4& a, int P) { return v2f{a.v[2 * P], a.v[2 * P + 1]}; }
 
 // ring geometry: PF rows of pointwise look-ahead (pp, v2, halo, ...); the p ring holds R rows,
 // R a multiple of PF (so queue slots are compile-time constants) and >= 2H+PF.
@@ -447,7 +520,6 @@ __device__ __forceinline__ void f4_store_rsrc(float* row, unsigned row_bytes, un
 template <int H, bool TAPER, int INJ, bool IMG, int PF>
 __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const int cs, const int xa, const int xe, f4* stash)
 {
-    constexpr int NW = 2 * H + 1;
     constexpr int R = ((2 * H + PF + PF - 1) / PF) * PF;   // ring turns == unroll factor (10 for H=4, PF=2)
     constexpr int LOOK = R - 2 * H;
     const size_t pitch = (size_t)a.pitch;
@@ -461,6 +533,7 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
 
     const bool wave_tap = TAPER && (cs * 4 < a.ztap);
     const bool xtap = wave_tap && ((xa - 2 * H < a.xt_lo) || (xe + 2 * H > a.xt_hi));
+    const CoefPairs<H> cpk = coef_pairs<H>(a.cx, a.cz);
     const bool inj_cols = (a.inj_z >= cs * 4) && (a.inj_z < cs * 4 + 256);
     // INJ == 1: point source at (inj_x, inj_z), samples inj[0] -> u^{n+1}, inj[1] -> u^{n+2}          (kernel_src, R:119-122)
     // INJ == 2: receiver row z = inj_z, rows [inj_x, inj_x+inj_n): inj[row-inj_x] -> u^{n+1}, inj2[..] -> u^{n+2} (kernel_sism)
@@ -498,8 +571,9 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
             for (int e = 0; e < 4; ++e) v.v[e] = taper1(v.v[e], tzc[e], znc[e], rowtz, txr);
         }
     };
-    auto load_p = [&](int row) -> f4 { return f4_load(a.p + (size_t)min(max(row, 0), rowmax) * pitch, voff); };
-    auto load_pw = [&](const float* base, int row) -> f4 { return f4_load(base + (size_t)min(max(row, 0), rowmax) * pitch, voff); };
+    auto rowoff = [&](int row) -> size_t { return (size_t)min(max(row, 0), rowmax) * pitch; };
+    auto load_p = [&](int row) -> f4 { return f4_load(a.p + rowoff(row), voff); };
+    auto load_pw = [&](const float* base, int row) -> f4 { return f4_load(base + rowoff(row), voff); };
 
     // march counter m = 0 .. M-1; step-1 row s = s0 + m, step-2 row r = s - H; ring1 row (b0 + k) lives in slot k % R
     const int s0 = xa - H, b0 = xa - 2 * H;
@@ -555,25 +629,28 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
                 if (a.pp_twice) taper_row(ppt, s);
             }
             const f4 c1 = ring1[(U + H) % R];
-            float W[12];
+            f4 lft, rgt;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                W[e] = __shfl_up(c1.v[e], 1, 64);
-                W[4 + e] = c1.v[e];
-                W[8 + e] = __shfl_down(c1.v[e], 1, 64);
+                lft.v[e] = __shfl_up(c1.v[e], 1, 64);
+                rgt.v[e] = __shfl_down(c1.v[e], 1, 64);
             }
             const bool rowok1 = (s >= a.lap_x0) && (s < a.lap_x1);
             const bool rowupd1 = (s >= 0) && (s < a.upd_x1);
             f4 u1;
+            {
+                const ZPairs zp = zpairs(lft, c1, rgt);
+                static_for<2>([&](auto PP) {
+                    constexpr int P = decltype(PP)::value;
+                    const v2f lap2 = laplacian_pair<H, P>(zp, [&](auto IO) { return f4_pair(ring1[(U + decltype(IO)::value) % R], P); }, cpk);
+                    const v2f prod2 = (f4_pair(qv2[Q], P) * a.dt2) * v2f{(rowok1 && mlap[2 * P]) ? lap2.x : 0.0f, (rowok1 && mlap[2 * P + 1]) ? lap2.y : 0.0f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float col[NW];
-#pragma unroll
-                for (int io = 0; io < NW; ++io) col[io] = ring1[(U + io) % R].v[e];
-                float lap = laplacian_pt<H>(W, e, col, a.cx, a.cz);
-                lap = (rowok1 && mlap[e]) ? lap : 0.0f;
-                const float upd = leapfrog_pt(c1.v[e], ppt.v[e], qv2[Q].v[e], a.dt2, lap);
-                u1.v[e] = (rowupd1 && mupd[e]) ? upd : ppt.v[e];
+                    for (int q = 0; q < 2; ++q) {
+                        const int e = 2 * P + q;
+                        const float upd = leapfrog_prod(c1.v[e], ppt.v[e], q ? prod2.y : prod2.x);
+                        u1.v[e] = (rowupd1 && mupd[e]) ? upd : ppt.v[e];
+                    }
+                });
             }
             if constexpr (INJ != 0) {
                 if (inj_here) {
@@ -585,7 +662,7 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
                     }
                 }
             }
-            f4_store_rsrc(a.out1 + (size_t)min(max(s, 0), rowmax) * pitch, row_bytes, soff1, u1);
+            f4_store_rsrc(a.out1 + rowoff(s), row_bytes, soff1, u1);
             if (wave_tap) taper_row(u1, s);                              // as "p" of step 2 it is damped once
             ring2[U] = u1;                                               // row s of u^{n+1}
             stash[((m & 7) << 6) + lane] = qv2[Q];                       // v2(s) is needed again H rows later: park it in LDS
@@ -598,21 +675,24 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
                 const f4 c2 = ring2[(U - H + R) % R];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    W[e] = __shfl_up(c2.v[e], 1, 64);
-                    W[4 + e] = c2.v[e];
-                    W[8 + e] = __shfl_down(c2.v[e], 1, 64);
+                    lft.v[e] = __shfl_up(c2.v[e], 1, 64);
+                    rgt.v[e] = __shfl_down(c2.v[e], 1, 64);
                 }
                 const bool rowok2 = (r >= a.lap_x0) && (r < a.lap_x1);
                 f4 u2;
+                {
+                    const ZPairs zp = zpairs(lft, c2, rgt);
+                    static_for<2>([&](auto PP) {
+                        constexpr int P = decltype(PP)::value;
+                        const v2f lap2 = laplacian_pair<H, P>(zp, [&](auto IO) { return f4_pair(ring2[(U - 2 * H + decltype(IO)::value + R) % R], P); }, cpk);
+                        const v2f prod2 = (f4_pair(v2r, P) * a.dt2) * v2f{(rowok2 && mlap[2 * P]) ? lap2.x : 0.0f, (rowok2 && mlap[2 * P + 1]) ? lap2.y : 0.0f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float col[NW];
-#pragma unroll
-                    for (int io = 0; io < NW; ++io) col[io] = ring2[(U - 2 * H + io + R) % R].v[e];
-                    float lap = laplacian_pt<H>(W, e, col, a.cx, a.cz);
-                    lap = (rowok2 && mlap[e]) ? lap : 0.0f;
-                    const float upd = leapfrog_pt(c2.v[e], pp2.v[e], v2r.v[e], a.dt2, lap);
-                    u2.v[e] = mupd[e] ? upd : pp2.v[e];
+                        for (int q = 0; q < 2; ++q) {
+                            const int e = 2 * P + q;
+                            const float upd = leapfrog_prod(c2.v[e], pp2.v[e], q ? prod2.y : prod2.x);
+                            u2.v[e] = mupd[e] ? upd : pp2.v[e];
+                        }
+                    });
                 }
                 if constexpr (INJ != 0) {
                     if (inj_here) {
@@ -624,7 +704,7 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
                         }
                     }
                 }
-                f4_store_rsrc(a.out2 + (size_t)min(max(r, 0), rowmax) * pitch, row_bytes, soff2, u2);
+                f4_store_rsrc(a.out2 + rowoff(r), row_bytes, soff2, u2);
                 if constexpr (IMG) {
                     // imaging condition of BOTH iterations at row r (kernel_img, R:133-144):  img += psrc_a * u^{n+1}, then
                     // img += psrc_b * u^{n+2}.  u^{n+1}(r) is ring2's centre row; where the image is extracted (interior) no
@@ -635,7 +715,7 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
                         im.v[e] = im.v[e] + qsa[Q].v[e] * c2.v[e];
                         im.v[e] = im.v[e] + qsb[Q].v[e] * u2.v[e];
                     }
-                    f4_store_rsrc(a.img + (size_t)min(max(r, 0), rowmax) * pitch, row_bytes, soff2, im);
+                    f4_store_rsrc(a.img + rowoff(r), row_bytes, soff2, im);
                 }
             }
             // ================= look-ahead loads into the slots this step freed =====================
@@ -656,7 +736,7 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
 }
 
 template <int H, bool TAPER, int INJ, bool IMG, int PF>
-__global__ __launch_bounds__(256) void fdw_step2_kernel(const Step2Args a)
+__global__ __launch_bounds__(256, IMG ? 3 : 4) void fdw_step2_kernel(const Step2Args a)
 {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
