@@ -397,6 +397,7 @@ extern "C" int fdw_dev_steps(fdw_ctx* c, float* d_p, float* d_pp, const float* d
 // ---- two time steps per pass (temporal blocking) --------------------------------------------------
 // The two-step kernel wins where a launch is bandwidth bound (>= 8192^2: +18 %, 16384^2: +47 %); on small decks a
 // launch is a latency chain and the longer march loses (new_mod: 12 vs 5 us/step), so the one-step kernel stays.
+constexpr long kPipeAutoStripRows = 1L << 60;   // auto-selection threshold of the wave-pipeline kernel (strip rows); off until measured
 static bool two_step_pays(const fdw_ctx* c)
 {
     if (c->h != kMaxFastHalfOrder || c->use_generic || c->tb < 0) return false;
@@ -476,6 +477,67 @@ static int step2_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
     return FDW_OK;
 }
 
+// ---- kPipeSteps time steps per pass (wave pipeline through LDS) -------------------------------------
+static bool pipe_pays(const fdw_ctx* c)
+{
+    if (c->h != kMaxFastHalfOrder || c->use_generic || c->tb < 0) return false;
+    if (c->tb == kPipeSteps) return true;
+    if (c->tb > 0) return false;                                   // two-step forced
+    return (long)c->upd_x1 * ((c->pitch / 4 + 55) / 56) >= kPipeAutoStripRows;
+}
+
+// FWD: d_inj -> kPipeSteps source samples srce[it .. it+kPipeSteps-1]; PLAIN: no taper, no injection.
+// d_out1 = u^{n+kPipeSteps-1}, d_out2 = u^{n+kPipeSteps}.
+static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp, const float* d_v2, float* d_out1, float* d_out2, int pp_twice,
+                      const float* d_inj, int inj_x_global, int inj_z, hipStream_t s)
+{
+    if (c->h != kMaxFastHalfOrder) return fail(FDW_EINVAL, "stepn: the pipelined kernel is built for order 8 only");
+    if (mode != FDW_MODE_FWD && mode != FDW_MODE_PLAIN) return fail(FDW_EINVAL, "stepn: FWD or PLAIN only");
+    if (!d_p || !d_pp || !d_v2 || !d_out1 || !d_out2) return fail(FDW_EINVAL, "stepn: NULL buffer");
+    if (d_out1 == d_p || d_out1 == d_pp || d_out2 == d_p || d_out2 == d_pp || d_out1 == d_out2)
+        return fail(FDW_EINVAL, "stepn: outputs must not alias the inputs (tiles re-read each other's input rows)");
+    Step2Args a{};
+    a.p = d_p; a.pp = d_pp; a.v2 = d_v2; a.out1 = d_out1; a.out2 = d_out2;
+    a.taperz = c->d_taperz; a.txfac = c->d_txfac; a.inj = d_inj;
+    a.pitch = c->pitch; a.nxl = c->nxl;
+    a.r0 = 0; a.r1 = c->upd_x1;
+    a.lap_x0 = c->lap_x0; a.lap_x1 = c->lap_x1; a.lap_z0 = c->lap_z0; a.lap_z1 = c->lap_z1;
+    a.upd_x1 = c->upd_x1; a.upd_z1 = c->upd_z1;
+    a.ztap = c->ztap; a.tz_x1 = c->tz_x1; a.xt_lo = c->xt_lo; a.xt_hi = c->xt_hi;
+    a.pp_twice = pp_twice ? 1 : 0;
+    a.inj_x = -1000000; a.inj_z = inj_z; a.inj_n = 0;
+    if (mode == FDW_MODE_FWD && d_inj && inj_x_global >= 0) {
+        if (inj_z < 0 || inj_z >= c->prm.nze || inj_x_global >= c->prm.nxe) return fail(FDW_EINVAL, "stepn: source (%d,%d) outside the grid", inj_x_global, inj_z);
+        a.inj_x = inj_x_global - c->slab.x_off;
+        if (a.inj_x >= c->upd_x1 && a.inj_x < c->nxl)
+            return fail(FDW_EINVAL, "stepn: source row %d lies in rows the reference never time-steps (>= %d)", inj_x_global, c->xlim);
+    }
+    a.dt2 = c->dt2;
+    for (int io = 0; io <= 2 * kMaxFastHalfOrder; io++) { a.cx[io] = c->cx[io]; a.cz[io] = c->cz[io]; }
+    const int ncells = c->pitch / 4, own = 64 - 2 * kPipeSteps;
+    a.nstrip = (ncells + own - 1) / own;
+    a.nzblk = a.nstrip;
+    const int rows = a.r1 - a.r0;
+    if (rows <= 0) return FDW_OK;
+    // whole ring turns: xchunk + (NS-1)(2H+1) = 10k  ->  xchunk = 10k - 27 (13, 23, ... 83, 93, ...)
+    const long strip_rows = (long)rows * a.nstrip;
+    int xchunk = c->xchunk2 > 0 ? c->xchunk2 : (strip_rows >= 1000000 ? 173 : (strip_rows >= 200000 ? 83 : 43));
+    a.xchunk = xchunk;
+    const int chunks = (rows + xchunk - 1) / xchunk;
+    a.nblk = a.nstrip * chunks;
+    a.nper = (a.nblk + 7) / 8;
+    hipError_t e = launch_stepn(a, c->h, mode, s);
+    if (e != hipSuccess) return fail(FDW_EHIP, "stepn launch failed: %s", hipGetErrorString(e));
+    // rows the reference never time-steps swap roles every step: after an even number of steps out1 carries pp's rows, out2 p's
+    static_assert(kPipeSteps % 2 == 0, "static-row bookkeeping assumes an even number of steps per pass");
+    if (c->upd_x1 < c->nxl) {
+        const size_t off = (size_t)c->upd_x1 * c->pitch, n = (size_t)(c->nxl - c->upd_x1) * c->pitch * sizeof(float);
+        HIP_TRY(hipMemcpyAsync(d_out1 + off, d_pp + off, n, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_out2 + off, d_p + off, n, hipMemcpyDeviceToDevice, s));
+    }
+    return FDW_OK;
+}
+
 extern "C" int fdw_two_step_active(const fdw_ctx* c) { return c && two_step_pays(c) ? 1 : 0; }
 
 extern "C" int fdw_dev_step2(fdw_ctx* c, const float* d_p, const float* d_pp, const float* d_v2, float* d_out1, float* d_out2, int pp_twice,
@@ -497,7 +559,16 @@ extern "C" int fdw_dev_steps2(fdw_ctx* c, float* const* buf, const float* d_v2, 
     int k = 0;
     while (k < nsteps) {
         const int twice = (k > 0) || first_pp_twice;
-        if (nsteps - k >= 2 && two_step_pays(c)) {
+        if (nsteps - k >= kPipeSteps && pipe_pays(c)) {
+            int o1 = 0, o2 = 0;
+            for (int i = 0, n = 0; i < 4; i++)
+                if (i != *ip && i != *ipp) { (n++ == 0 ? o1 : o2) = i; }
+            int rc = stepn_impl(c, FDW_MODE_FWD, buf[*ipp], buf[*ip], d_v2, buf[o1], buf[o2], twice, d_srce ? d_srce + it0 + k : nullptr,
+                                d_srce ? sx : -1, sz, s);
+            if (rc) return rc;
+            *ip = o1; *ipp = o2;   // d_p = u^{n+kPipeSteps-1}, d_pp = u^{n+kPipeSteps}
+            k += kPipeSteps;
+        } else if (nsteps - k >= 2 && two_step_pays(c)) {
             int o1 = 0, o2 = 0;   // the two buffers not holding the current pair
             for (int i = 0, n = 0; i < 4; i++)
                 if (i != *ip && i != *ipp) { (n++ == 0 ? o1 : o2) = i; }
@@ -807,7 +878,7 @@ extern "C" int fdw_set_tuning(fdw_ctx* c, int xchunk, int wz, int use_generic, i
     c->wz = wz;
     c->use_generic = use_generic ? 1 : 0;
     c->prefetch = prefetch;
-    c->tb = two_step < 0 ? -1 : (two_step > 0 ? 1 : 0);
+    c->tb = two_step < 0 ? -1 : (two_step == kPipeSteps ? kPipeSteps : (two_step > 0 ? 1 : 0));   // kPipeSteps: force the wave-pipeline kernel
     c->xchunk2 = xchunk;   // the two-step kernel shares the knob (0 = its own default)
     return FDW_OK;
 }

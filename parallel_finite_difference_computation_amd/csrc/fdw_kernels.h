@@ -67,6 +67,12 @@ struct Step2Args {
 };
 hipError_t launch_step2(const Step2Args& a, int half_order, int mode, hipStream_t s);
 
+// kPipeSteps time steps per pass (wave pipeline through LDS, order 8, FWD / PLAIN): see fdw_stepn_kernel.  Uses Step2Args with
+// out1 = u^{n+kPipeSteps-1}, out2 = u^{n+kPipeSteps}, inj -> kPipeSteps source samples, nstrip = strips of 64-2*kPipeSteps cells,
+// nblk = nstrip * chunks workgroups of kPipeSteps waves.
+constexpr int kPipeSteps = 4;
+hipError_t launch_stepn(const Step2Args& a, int half_order, int mode, hipStream_t s);
+
 hipError_t launch_step_fast(const StepArgs& a, int half_order, int mode, int prefetch, hipStream_t s);
 hipError_t launch_step_generic(const StepArgs& a, int half_order, int mode, hipStream_t s);
 hipError_t launch_taper_finalize(float* f, const float* taperz, const float* txfac, int pitch, int nxl, int ztap,

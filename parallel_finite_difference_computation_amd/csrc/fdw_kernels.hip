@@ -49,7 +49,7 @@ namespace fdw {
 // ------------------------------------------------------------------------------------------------
 // Timing experiments only (scripts/build_ablations.sh builds throw-away libraries with -DFDW_ABL_BITS=n; any bit
 // breaks the results): 1 fp32 update, 2 no strip-halo load, 4 no store, 8 no lane exchange, 16 trivial Laplacian,
-// 32 every row aliases row 0 (loads become cache hits: pure issue/VALU time).
+// 32 every row aliases row 0 (loads become cache hits: pure issue/VALU time), 64 pipeline kernel without its barriers.
 #ifndef FDW_ABL_BITS
 #define FDW_ABL_BITS 0
 #endif
@@ -756,6 +756,214 @@ __global__ __launch_bounds__(256, IMG ? 3 : 4) void fdw_step2_kernel(const Step2
 }
 
 // ------------------------------------------------------------------------------------------------
+// NS time steps per pass: a pipeline of NS waves per workgroup, one wave per time level, rows handed from
+// wave to wave through LDS.  Wave k (k = 0..NS-1) computes u^{n+k+1}; only wave 0 reads global memory
+// (u^n, u^{n-1}, v2) and only the last two waves write it (u^{n+NS-1} -> out1, u^{n+NS} -> out2), so a
+// pass moves 12 B in + 8 B out per point for NS steps instead of per step.
+//
+// Every wave is the one-step march on a register ring of 2H+1 rows of "its" p field.  At march step m wave k
+// works on row r_k(m) = xa - (NS-1)H - k(H+1) + m: a skew of H+1 rows per stage, so that what wave k-1
+// produced during step m-1 (its result row r_{k-1}(m-1) = r_k(m)+H, which enters wave k's window, and the
+// row its own window dropped, r_{k-1}(m-1)-H = r_k(m), which is wave k's "pp") is consumed during step m;
+// one workgroup barrier per march step separates producer and consumer, link buffers alternate by the parity
+// of m.  v2 rows ride a 16-row LDS FIFO filled by wave 0.  All waves run IDENTICAL code: the global loads of
+// waves k > 0 are sent out of range through the buffer descriptor (no memory request, zeros returned) and the
+// stores of waves < NS-2 likewise, so the s_waitcnt counting stays exact and nothing diverges.
+// Validity: wave k's rows are good from march step k(2H+1) on (its window then holds only good rows of wave
+// k-1); in z every step costs H = one lane per side, so NS lanes per side of a wave are halo and 64-2NS owned.
+// Per point and step the arithmetic is the one-step kernel's (packed pairs as in the two-step kernel).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f4 f4_load_rsrc(const float* row, unsigned row_bytes, unsigned voff_bytes, bool nt)
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, row_bytes, 0x00020000);
+    const v4u t = nt ? __builtin_amdgcn_raw_buffer_load_b128(rs, voff_bytes, 0, 2) : __builtin_amdgcn_raw_buffer_load_b128(rs, voff_bytes, 0, 0);
+    const v4f r = __builtin_bit_cast(v4f, t);
+    f4 o;
+    o.v[0] = r.x; o.v[1] = r.y; o.v[2] = r.z; o.v[3] = r.w;
+    return o;
+}
+
+constexpr int kFifoRows = 16;   // v2 FIFO depth: > (NS-1)(H+1) for NS = 4, H = 4
+
+template <int H, int NS, bool TAPER, int INJ, int PF>
+__device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const int k, const int cs, const int xa, const int xe,
+                                       f4 (*link)[2][2][64], f4 (*fifo)[64])
+{
+    static_assert((NS - 1) * (H + 1) < kFifoRows, "v2 FIFO too short");
+    constexpr int R = ((2 * H + PF + PF - 1) / PF) * PF;
+    constexpr int LOOK = R - 2 * H;
+    constexpr int SK = H + 1;
+    const bool first = (k == 0);
+    const size_t pitch = (size_t)a.pitch;
+    const int cell = cs + lane;
+    const int z0 = cell * 4;
+    const unsigned voff = (unsigned)min(max(z0, 0), a.pitch - 4) * 4u;
+    const bool own = (lane >= NS) && (lane <= 63 - NS) && (z0 >= 0) && (z0 < a.pitch);
+    const unsigned soff = (own && k >= NS - 2) ? voff : 0xFFFFFFF0u;     // only the last two waves store
+    const unsigned loff = first ? voff : 0xFFFFFFF0u;                     // only wave 0 loads
+    float* const outp = (k == NS - 1) ? a.out2 : a.out1;
+    const unsigned row_bytes = (unsigned)a.pitch * 4u;
+    const int rowmax = a.nxl - 1;
+
+    const bool wave_tap = TAPER && (cs * 4 < a.ztap);
+    const bool xtap = wave_tap && ((xa - NS * H < a.xt_lo) || (xe + NS * H > a.xt_hi));
+    const CoefPairs<H> cpk = coef_pairs<H>(a.cx, a.cz);
+    const bool inj_here = (INJ == 1) && (a.inj_z >= cs * 4) && (a.inj_z < cs * 4 + 256) && (a.inj_x >= xa - NS * H) && (a.inj_x < xe + NS * H);
+    const float injv = inj_here ? sload(a.inj, k) : 0.0f;                 // source sample of this wave's time step (R:119-122)
+
+    bool mlap[4], mupd[4], znc[4], ihit[4];
+    float tzc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int z = z0 + e;
+        mlap[e] = (z >= a.lap_z0) && (z < a.lap_z1);
+        mupd[e] = (z >= 0) && (z < a.upd_z1);
+        ihit[e] = (z == a.inj_z);
+        znc[e] = (z >= 0) && (z < a.ztap);
+        tzc[e] = 1.0f;
+    }
+    if (wave_tap) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (znc[e]) tzc[e] = a.taperz[z0 + e];
+    }
+    auto taper_row = [&](f4& v, int row) {
+        if (!xtap) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = v.v[e] * tzc[e];
+        } else {
+            const int rc = min(max(row, 0), a.nxl - 1);
+            const float txr = sload(a.txfac, rc);
+            const bool rowtz = row < a.tz_x1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = taper1(v.v[e], tzc[e], znc[e], rowtz, txr);
+        }
+    };
+    auto rowoff = [&](int row) -> size_t { return (size_t)min(max(row, 0), rowmax) * pitch; };
+    auto load_p = [&](int row) -> f4 { return f4_load_rsrc(a.p + rowoff(row), row_bytes, loff, (FDW_NT & 4) != 0); };
+    auto load_pw = [&](const float* base, int row) -> f4 { return f4_load_rsrc(base + rowoff(row), row_bytes, loff, (FDW_NT & 1) != 0); };
+
+    // rows: wave 0's centre row at march step m is s0 + m (what the global loads follow); this wave's is rk + m
+    const int s0 = xa - (NS - 1) * H, b0 = s0 - H;
+    const int rk = s0 - k * SK;
+    const int M = (xe - xa) + (NS - 1) * (2 * H + 1);
+    const int kp = max(k - 1, 0);
+    f4 ring[R];
+    f4 qpp[PF], qv2[PF];
+    constexpr int NV = LOOK > PF ? LOOK : PF;
+    static_for<2 * H>([&](auto K) {
+        constexpr int kk = decltype(K)::value;
+        ring[kk] = load_p(b0 + kk);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    static_for<NV>([&](auto JJ) {
+        constexpr int j = decltype(JJ)::value - NV;
+        if constexpr (j >= -LOOK) ring[j + 2 * H + LOOK] = load_p(b0 + j + 2 * H + LOOK);
+        if constexpr (j >= -PF) {
+            constexpr int mm = j + PF;
+            qpp[mm] = load_pw(a.pp, s0 + mm);
+            qv2[mm] = load_pw(a.v2, s0 + mm);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    if (wave_tap) {
+        static_for<2 * H>([&](auto K) {
+            constexpr int kk = decltype(K)::value;
+            taper_row(ring[kk], b0 + kk);
+        });
+    }
+
+    auto row_step = [&](const int mb, auto UU) {
+        constexpr int U = decltype(UU)::value;
+        constexpr int Q = U % PF;
+        constexpr int E = (U + 2 * H) % R;                      // slot of the row entering the window this step
+        const int m = mb + U;
+        const int r = rk + m;
+        const int par = m & 1;
+        // ---- what the previous wave handed over during march step m-1 ----
+        const f4 nr = link[kp][par ^ 1][0][lane];
+        const f4 ppl = link[kp][par ^ 1][1][lane];
+        const f4 v2l = fifo[(m - k * SK) & (kFifoRows - 1)][lane];
+        f4 ppt, v2t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ring[E].v[e] = first ? ring[E].v[e] : nr.v[e];
+            ppt.v[e] = first ? qpp[Q].v[e] : ppl.v[e];
+            v2t.v[e] = first ? qv2[Q].v[e] : v2l.v[e];
+        }
+        if (first) fifo[m & (kFifoRows - 1)][lane] = qv2[Q];
+        if (wave_tap) {
+            taper_row(ring[E], r + H);                          // entering row: damped once as "p" of this step
+            taper_row(ppt, r);                                  // "pp": from memory once (+ once owed), from LDS once more
+            if (first && a.pp_twice) taper_row(ppt, r);
+        }
+        const f4 c1 = ring[(U + H) % R];
+        f4 lft, rgt;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lft.v[e] = __shfl_up(c1.v[e], 1, 64);
+            rgt.v[e] = __shfl_down(c1.v[e], 1, 64);
+        }
+        const bool rowok = (r >= a.lap_x0) && (r < a.lap_x1);
+        const bool rowupd = (r >= 0) && (r < a.upd_x1);
+        f4 u;
+        {
+            const ZPairs zp = zpairs(lft, c1, rgt);
+            static_for<2>([&](auto PP) {
+                constexpr int P = decltype(PP)::value;
+                const v2f lap2 = laplacian_pair<H, P>(zp, [&](auto IO) { return f4_pair(ring[(U + decltype(IO)::value) % R], P); }, cpk);
+                const v2f prod2 = (f4_pair(v2t, P) * a.dt2) * v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = 2 * P + q;
+                    const float upd = leapfrog_prod(c1.v[e], ppt.v[e], q ? prod2.y : prod2.x);
+                    u.v[e] = (rowupd && mupd[e]) ? upd : ppt.v[e];
+                }
+            });
+        }
+        if constexpr (INJ == 1) {
+            if (inj_here && r == a.inj_x) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u.v[e] = ihit[e] ? u.v[e] + injv : u.v[e];
+            }
+        }
+        // ---- hand over to the next wave: the new row (raw) and the row leaving this window (damped once) ----
+        link[k][par][0][lane] = u;
+        link[k][par][1][lane] = ring[U];
+        const unsigned so = ((r >= xa) && (r < xe) && (m < M)) ? soff : 0xFFFFFFF0u;
+        f4_store_rsrc(outp + rowoff(r), row_bytes, so, u);
+        // ---- look-ahead loads of wave 0 into the slots this step freed ----
+        ring[U] = load_p(b0 + m + R);
+        qpp[Q] = load_pw(a.pp, s0 + m + PF);
+        qv2[Q] = load_pw(a.v2, s0 + m + PF);
+#if !(FDW_ABL_BITS & 64)
+        __syncthreads();
+#endif
+    };
+
+    for (int mb = 0; mb < M; mb += R)
+        static_for<R>([&](auto UU) { row_step(mb, UU); });
+}
+
+template <int H, int NS, bool TAPER, int INJ, int PF>
+__global__ __launch_bounds__(64 * NS, 4) void fdw_stepn_kernel(const Step2Args a)
+{
+    const int lane = threadIdx.x & 63;
+    const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bid = blockIdx.x;
+    const int L = (bid & 7) * a.nper + (bid >> 3);
+    if (L >= a.nblk) return;                    // whole workgroups only: every barrier below is reached by all NS waves
+    const int zb = L % a.nstrip;
+    const int xb = L / a.nstrip;
+    const int xa = a.r0 + xb * a.xchunk;
+    const int xe = min(xa + a.xchunk, a.r1);
+    if (xa >= xe) return;
+    __shared__ f4 link[NS][2][2][64];           // [producer wave][parity of m][0 new row | 1 row leaving the window][lane]
+    __shared__ f4 fifo[kFifoRows][64];
+    marchn<H, NS, TAPER, INJ, PF>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo);
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic-order kernel: any even order up to FDW_MAX_ORDER, one thread per point, every tap from
 // global memory (L1/L2 absorb the reuse).  Same arithmetic, same lazy-taper rules; used for orders
 // the register-ring kernel is not instantiated for, and as an independent cross-check of it.
@@ -882,6 +1090,19 @@ hipError_t launch_step2(const Step2Args& a, int h, int mode, hipStream_t s)
     case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_step2_kernel<4, true, 1, false, 2>), grid, block, 0, s, a); break;
     case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_step2_kernel<4, false, 0, false, 2>), grid, block, 0, s, a); break;
     case FDW_MODE_RECV:  hipLaunchKernelGGL((fdw_step2_kernel<4, true, 2, true, 2>), grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_stepn(const Step2Args& a, int h, int mode, hipStream_t s)
+{
+    if (a.nper <= 0) return hipSuccess;
+    if (h != 4) return hipErrorInvalidValue;
+    const dim3 grid(8 * a.nper), block(64 * kPipeSteps);
+    switch (mode) {
+    case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 1, 2>), grid, block, 0, s, a); break;
+    case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, false, 0, 2>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

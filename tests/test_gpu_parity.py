@@ -410,10 +410,11 @@ def test_two_step_kernel_vs_oracle_bit_exact(case):
     v2 = torch.zeros((nxe, ctx.pitch), device=dev)
     v2[:, :nze] = torch.from_numpy(d["v2"]).to(dev)
     ts = torch.cuda.Stream()
-    for init in ("rest", "random"):
+    for init, mode in (("rest", 1), ("random", 1), ("rest", 4), ("random", 4)):   # 1: two steps per pass, 4: the four-wave pipeline
         for nsteps in (2, 5, 8, 13):
             for xchunk in (0, 7, 20):
-                ctx.set_tuning(xchunk=xchunk)
+                ctx.set_tuning(xchunk=xchunk, two_step=mode)
+                assert ctx.two_step_active()
                 bufs = [torch.zeros((nxe, ctx.pitch), device=dev) for _ in range(4)]
                 hp, hpp = (None, None) if init == "rest" else (p0, pp0)
                 if init == "random":
@@ -430,7 +431,7 @@ def test_two_step_kernel_vs_oracle_bit_exact(case):
                     ctx.dev_taper_finalize(bufs[ip].data_ptr(), stream=ts.cuda_stream)
                 torch.cuda.synchronize()
                 oP, oPP = orc.forward(d["v2"], d["sx"], d["sz"], srce_h, hp, hpp, nsteps=nsteps)
-                tag = f"{init} nsteps={nsteps} xchunk={xchunk}"
+                tag = f"{init} mode={mode} nsteps={nsteps} xchunk={xchunk}"
                 assert_bit_equal(bufs[ipp][:, :nze].cpu().numpy(), oPP, "PP " + tag)
                 assert_bit_equal(bufs[ip][:, :nze].cpu().numpy(), oP, "P " + tag)
 
@@ -460,7 +461,7 @@ def test_edge_decks_forward_back_and_two_step(case):
     srce = O.ricker_wavelet(nt, d["dt"], 30.0)
     p0, pp0 = random_fields(d, seed=3, amp=0.1)
     ctx, orc = mk(d), mko(d)
-    for two_step in (-1, 1) if order == 8 else (0,):
+    for two_step in (-1, 1, 4) if order == 8 else (0,):
         ctx.set_tuning(two_step=two_step)
         for p, pp, n in ((None, None, nt), (p0, pp0, nt), (p0, pp0, 3)):
             P, PP = ctx.forward(d["v2"], d["sx"], d["sz"], srce, p, pp, nsteps=n)
@@ -477,10 +478,11 @@ def test_source_position_sweep_two_step():
     d = make_deck(130, 560, 10, 12, 6, seed=9, compat=False)
     srce = np.array([1.0, -2.0, 3.0, 0.5, -1.5, 2.5], np.float32)
     ctx, orc = mk(d), mko(d)
-    ctx.set_tuning(two_step=1, xchunk=12)
-    for sx in (10, 11, 12, 13, 21, 22, 23, 34, 64, 119):
-        for sz in (12, 239, 240, 241, 247, 248, 479, 480, 481, 547):
-            P, PP = ctx.forward(d["v2"], sx, sz, srce)
-            oP, oPP = orc.forward(d["v2"], sx, sz, srce)
-            assert_bit_equal(PP, oPP, f"PP source at ({sx},{sz})")
-            assert_bit_equal(P, oP, f"P source at ({sx},{sz})")
+    for mode, xchunk, szs in ((1, 12, (12, 239, 240, 241, 247, 248, 479, 480, 481, 547)), (4, 13, (12, 207, 208, 223, 224, 225, 239, 240, 447, 448, 547))):
+        ctx.set_tuning(two_step=mode, xchunk=xchunk)     # strips own 240 columns (two-step) / 224 columns (pipeline)
+        for sx in (10, 11, 12, 13, 21, 22, 23, 34, 64, 119):
+            for sz in szs:
+                P, PP = ctx.forward(d["v2"], sx, sz, srce)
+                oP, oPP = orc.forward(d["v2"], sx, sz, srce)
+                assert_bit_equal(PP, oPP, f"PP mode {mode} source at ({sx},{sz})")
+                assert_bit_equal(P, oP, f"P mode {mode} source at ({sx},{sz})")
