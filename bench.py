@@ -240,15 +240,17 @@ def main():
             "result_finite_nonzero": finite,
         }
         if world == 1:
-            two = ctx.two_step_active()
-            steps_per_launch = 2 if two else 1
-            launches = (K // 2 + K % 2) if two else K
+            steps_per_launch = ctx.steps_per_pass()          # 4: wave pipeline, 2: two-step kernel, 1: one-step kernel
+            rem = K % steps_per_launch
+            launches = K // steps_per_launch + (rem // 2 + rem % 2 if ctx.two_step_active() else rem)
+            kname = {4: "fdw::fdw_stepn_kernel<4,4,true,1,2> (four time steps per launch: one wave per time level, rows handed through LDS)",
+                     2: "fdw::fdw_step2_kernel<4,true,1,false,2> (two time steps per launch)", 1: "fdw::fdw_step_kernel<4,true,1,false,false,2>"}[steps_per_launch]
             launch_ms = dev_ms / launches
             algo = ALGO_BYTES_PER_POINT * pts_per_launch * steps_per_launch      # 16 B/point/step x steps in one launch
             achieved = algo / (launch_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                               "kernel": "fdw::fdw_step2_kernel<4,true,2> (two time steps per launch)" if two else "fdw::fdw_step_kernel<4,true,1,false,false,2>",
+                               "kernel": kname,
                                "launch_us": round(launch_ms * 1e3, 2), "steps_per_launch": steps_per_launch,
                                "algorithmic_bytes_per_launch": algo}
             traffic_file = os.path.join(ROOT, "profiles", "traffic.json")

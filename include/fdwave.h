@@ -156,7 +156,8 @@ int fdw_download_field(fdw_ctx *ctx, float *h_dst, const float *d_src);
  * fdw_set_tuning  xchunk = rows marched per wave (0 = auto), wz = waves of a block laid along z
  *                 (1,2,4; 0 = auto), use_generic = force the generic-order kernel (tests),
  *                 prefetch = software prefetch distance in rows (0 = default; 1..3, order 8 only),
- *                 two_step = temporal blocking in the forward loops: 0 auto (grids >= 8192^2), 1 always, -1 never.
+ *                 two_step = temporal blocking in the forward loops: 0 auto (by grid size), 1 two steps per pass always,
+ *                 4 the four-steps-per-pass wave pipeline always, -1 never.
  * fdw_get_tables  copies of the derived host tables (any pointer may be NULL):
  *                 coefs_x/z[order+1] (R:214-217), taper_x[nxb], taper_z[nzb] (R:159-166).
  * fdw_get_extents xlim/zlim = rows/columns the time update covers, ztap = damped columns (R:185-195).
@@ -167,6 +168,7 @@ int fdw_set_tuning(fdw_ctx *ctx, int xchunk, int wz, int use_generic, int prefet
 int fdw_get_tables(const fdw_ctx *ctx, float *coefs_x, float *coefs_z, float *taper_x, float *taper_z);
 int fdw_get_extents(const fdw_ctx *ctx, int *xlim, int *zlim, int *ztap);
 int fdw_two_step_active(const fdw_ctx *ctx); /* 1 if the forward loops of this context use the two-step kernel */
+int fdw_steps_per_pass(const fdw_ctx *ctx);  /* time steps one launch of the forward loops advances: 4 (wave pipeline), 2 or 1 */
 int fdw_selftest(fdw_ctx *ctx);
 
 /* ---- host formulas of libsource.a restated (pure C, usable without a device) --------------------

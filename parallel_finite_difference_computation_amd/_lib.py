@@ -57,6 +57,7 @@ SIGNATURES = [
     ("fdw_get_tables", C.c_int, [vp, vp, vp, vp, vp]),
     ("fdw_get_extents", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("fdw_two_step_active", C.c_int, [vp]),
+    ("fdw_steps_per_pass", C.c_int, [vp]),
     ("fdw_selftest", C.c_int, [vp]),
     ("fdw_calc_coefs", C.c_int, [C.c_int, C.c_int, f32p]),
     ("fdw_ricker_wavelet", None, [C.c_int, C.c_float, C.c_float, f32p]),

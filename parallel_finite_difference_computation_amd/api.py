@@ -101,11 +101,15 @@ class FDWave:
         return a.value, b.value, c.value
 
     def set_tuning(self, xchunk=0, wz=0, use_generic=False, prefetch=0, two_step=0, force_edge=False):
-        """two_step: 0 auto, 1 always, -1 never (temporal blocking in forward loops).  force_edge is obsolete and ignored."""
+        """two_step: 0 auto, 1 two steps per pass, 4 the four-wave pipeline, -1 never (temporal blocking in forward loops).  force_edge is obsolete and ignored."""
         check(lib().fdw_set_tuning(self._h, xchunk, wz, int(use_generic), prefetch, int(two_step)))
 
     def two_step_active(self):
         return bool(lib().fdw_two_step_active(self._h))
+
+    def steps_per_pass(self):
+        """Time steps one launch of the forward loops advances on this grid: 4 (wave pipeline), 2 (two-step kernel) or 1."""
+        return int(lib().fdw_steps_per_pass(self._h))
 
     def selftest(self):
         check(lib().fdw_selftest(self._h))

@@ -397,7 +397,9 @@ extern "C" int fdw_dev_steps(fdw_ctx* c, float* d_p, float* d_pp, const float* d
 // ---- two time steps per pass (temporal blocking) --------------------------------------------------
 // The two-step kernel wins where a launch is bandwidth bound (>= 8192^2: +18 %, 16384^2: +47 %); on small decks a
 // launch is a latency chain and the longer march loses (new_mod: 12 vs 5 us/step), so the one-step kernel stays.
-constexpr long kPipeAutoStripRows = 1L << 60;   // auto-selection threshold of the wave-pipeline kernel (strip rows); off until measured
+// Auto-selection threshold of the wave-pipeline kernel, in strip rows (rows x strips of 56 cells).  Measured (scripts/probe_sizes.py,
+// probe_slabsize.py): 2048^2 (20k) one-step 280 vs pipeline 253 Gpt/s; 1056x8192 (39k) 312 vs 371; 4096^2 (78k) 337 (two-step 360) vs 452.
+constexpr long kPipeAutoStripRows = 30000;
 static bool two_step_pays(const fdw_ctx* c)
 {
     if (c->h != kMaxFastHalfOrder || c->use_generic || c->tb < 0) return false;
@@ -481,6 +483,7 @@ static int step2_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
 static bool pipe_pays(const fdw_ctx* c)
 {
     if (c->h != kMaxFastHalfOrder || c->use_generic || c->tb < 0) return false;
+    if ((size_t)c->nxl * c->pitch * sizeof(float) >= (1ull << 31)) return false;   // the kernel addresses a field through one 2 GiB buffer descriptor
     if (c->tb == kPipeSteps) return true;
     if (c->tb > 0) return false;                                   // two-step forced
     return (long)c->upd_x1 * ((c->pitch / 4 + 55) / 56) >= kPipeAutoStripRows;
@@ -521,7 +524,9 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
     if (rows <= 0) return FDW_OK;
     // whole ring turns: xchunk + (NS-1)(2H+1) = 10k  ->  xchunk = 10k - 27 (13, 23, ... 83, 93, ...)
     const long strip_rows = (long)rows * a.nstrip;
-    int xchunk = c->xchunk2 > 0 ? c->xchunk2 : (strip_rows >= 1000000 ? 173 : (strip_rows >= 200000 ? 83 : 43));
+    // measured: 16384^2 579 Gpt/s at 253 (560 at 173); 8192^2 566 at 173 (509 at 83, 553 at 253); 4096^2 452 at 83 (382 at 43, 388 at 173);
+    // 1056x8192 371 at 43 (355 at 63, 340 at 33)
+    int xchunk = c->xchunk2 > 0 ? c->xchunk2 : (strip_rows >= 1000000 ? 253 : (strip_rows >= 250000 ? 173 : (strip_rows >= 60000 ? 83 : 43)));
     a.xchunk = xchunk;
     const int chunks = (rows + xchunk - 1) / xchunk;
     a.nblk = a.nstrip * chunks;
@@ -539,6 +544,7 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
 }
 
 extern "C" int fdw_two_step_active(const fdw_ctx* c) { return c && two_step_pays(c) ? 1 : 0; }
+extern "C" int fdw_steps_per_pass(const fdw_ctx* c) { return !c ? 0 : (pipe_pays(c) ? kPipeSteps : (two_step_pays(c) ? 2 : 1)); }
 
 extern "C" int fdw_dev_step2(fdw_ctx* c, const float* d_p, const float* d_pp, const float* d_v2, float* d_out1, float* d_out2, int pp_twice,
                              const float* d_srce_it, int sx, int sz, void* stream)

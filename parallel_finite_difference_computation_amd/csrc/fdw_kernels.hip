@@ -49,7 +49,8 @@ namespace fdw {
 // ------------------------------------------------------------------------------------------------
 // Timing experiments only (scripts/build_ablations.sh builds throw-away libraries with -DFDW_ABL_BITS=n; any bit
 // breaks the results): 1 fp32 update, 2 no strip-halo load, 4 no store, 8 no lane exchange, 16 trivial Laplacian,
-// 32 every row aliases row 0 (loads become cache hits: pure issue/VALU time), 64 pipeline kernel without its barriers.
+// 32 every row aliases row 0 (loads become cache hits: pure issue/VALU time), 64 pipeline kernel without its barriers;
+// pipeline kernel only: 128 no LDS hand-over, 256 trivial Laplacian, 512 fp32 update, 1024 no global loads/stores in the march, 2048 no lane exchange.
 #ifndef FDW_ABL_BITS
 #define FDW_ABL_BITS 0
 #endif
@@ -131,8 +132,13 @@ __device__ __forceinline__ float laplacian_pt(const float* W, int e, const float
 // the update once prod = (v2*dt2)*lap is formed (fp32, as the reference's float expression does; R:89)
 __device__ __forceinline__ float leapfrog_prod(float p, float pp, float prod)
 {
-    const double d = 2.0 * (double)p - (double)pp + (double)prod;
-    return (float)d;
+    // 2.*p - pp: the product is exact in double, so the fused form rounds once exactly like the reference's two operations
+    const double d = __builtin_fma(2.0, (double)p, -(double)pp) + (double)prod;
+    float r = (float)d;
+    // Keep the update unconditional: without this hipcc turns the caller's "mask ? update : old" select into a branch
+    // around the fp64 chain (one serial basic block per cell, nothing to interleave with).
+    asm volatile("" : "+v"(r));
+    return r;
 }
 __device__ __forceinline__ float leapfrog_pt(float p, float pp, float v2, float dt2, float lap)
 {
@@ -156,6 +162,7 @@ struct ZPairs {
 };
 __device__ __forceinline__ ZPairs zpairs(const f4& left, const f4& c, const f4& right)
 {
+    // (the odd pairs cost two v_mov_b32 each; forming them with v_pk_mov_b32 through asm made hipcc keep half of the ring in scratch)
     ZPairs z;
     z.E[0] = v2f{left.v[0], left.v[1]};   z.E[1] = v2f{left.v[2], left.v[3]};
     z.E[2] = v2f{c.v[0], c.v[1]};         z.E[3] = v2f{c.v[2], c.v[3]};
@@ -736,7 +743,7 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
 }
 
 template <int H, bool TAPER, int INJ, bool IMG, int PF>
-__global__ __launch_bounds__(256, IMG ? 3 : 4) void fdw_step2_kernel(const Step2Args a)
+__global__ __launch_bounds__(256, IMG ? 3 : (TAPER ? 4 : 2)) void fdw_step2_kernel(const Step2Args a)
 {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -783,6 +790,31 @@ __device__ __forceinline__ f4 f4_load_rsrc(const float* row, unsigned row_bytes,
     return o;
 }
 
+// Whole-array descriptors: the row goes in as the scalar offset (one s_mul per row instead of a 64-bit address and a fresh
+// descriptor per row and stream), the lane's column as the vector offset.  A lane is switched off with kLaneOff, which is out
+// of range of any array the host admits (< 2 GiB) whether or not the hardware adds the scalar offset before its range check.
+constexpr unsigned kLaneOff = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t array_rsrc(const float* base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f4 f4_load_arr(__amdgpu_buffer_rsrc_t rs, unsigned voff_bytes, unsigned row_off_bytes, bool nt)
+{
+    const v4u t = nt ? __builtin_amdgcn_raw_buffer_load_b128(rs, voff_bytes, row_off_bytes, 2) : __builtin_amdgcn_raw_buffer_load_b128(rs, voff_bytes, row_off_bytes, 0);
+    const v4f r = __builtin_bit_cast(v4f, t);
+    f4 o;
+    o.v[0] = r.x; o.v[1] = r.y; o.v[2] = r.z; o.v[3] = r.w;
+    return o;
+}
+__device__ __forceinline__ void f4_store_arr(__amdgpu_buffer_rsrc_t rs, unsigned voff_bytes, unsigned row_off_bytes, const f4& a)
+{
+    const v4f t = {a.v[0], a.v[1], a.v[2], a.v[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), rs, voff_bytes, row_off_bytes, (FDW_NT & 2) ? 2 : 0);
+}
+
+#ifndef FDW_PIPE_PF
+#define FDW_PIPE_PF 2      // rows of global look-ahead of wave 0
+#endif
 constexpr int kFifoRows = 16;   // v2 FIFO depth: > (NS-1)(H+1) for NS = 4, H = 4
 
 template <int H, int NS, bool TAPER, int INJ, int PF>
@@ -794,16 +826,18 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
     constexpr int LOOK = R - 2 * H;
     constexpr int SK = H + 1;
     const bool first = (k == 0);
-    const size_t pitch = (size_t)a.pitch;
+    static_assert(R % 2 == 0, "link parity is taken from the unroll index");
     const int cell = cs + lane;
     const int z0 = cell * 4;
     const unsigned voff = (unsigned)min(max(z0, 0), a.pitch - 4) * 4u;
     const bool own = (lane >= NS) && (lane <= 63 - NS) && (z0 >= 0) && (z0 < a.pitch);
-    const unsigned soff = (own && k >= NS - 2) ? voff : 0xFFFFFFF0u;     // only the last two waves store
-    const unsigned loff = first ? voff : 0xFFFFFFF0u;                     // only wave 0 loads
-    float* const outp = (k == NS - 1) ? a.out2 : a.out1;
+    const unsigned soff = (own && k >= NS - 2) ? voff : kLaneOff;         // only the last two waves store
+    const unsigned loff = first ? voff : kLaneOff;                        // only wave 0 loads
     const unsigned row_bytes = (unsigned)a.pitch * 4u;
     const int rowmax = a.nxl - 1;
+    const unsigned arr_bytes = (unsigned)a.nxl * row_bytes;               // < 2 GiB (checked by the host)
+    const __amdgpu_buffer_rsrc_t rs_p = array_rsrc(a.p, arr_bytes), rs_pp = array_rsrc(a.pp, arr_bytes), rs_v2 = array_rsrc(a.v2, arr_bytes);
+    const __amdgpu_buffer_rsrc_t rs_out = array_rsrc((k == NS - 1) ? a.out2 : a.out1, arr_bytes);
 
     const bool wave_tap = TAPER && (cs * 4 < a.ztap);
     const bool xtap = wave_tap && ((xa - NS * H < a.xt_lo) || (xe + NS * H > a.xt_hi));
@@ -839,9 +873,9 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             for (int e = 0; e < 4; ++e) v.v[e] = taper1(v.v[e], tzc[e], znc[e], rowtz, txr);
         }
     };
-    auto rowoff = [&](int row) -> size_t { return (size_t)min(max(row, 0), rowmax) * pitch; };
-    auto load_p = [&](int row) -> f4 { return f4_load_rsrc(a.p + rowoff(row), row_bytes, loff, (FDW_NT & 4) != 0); };
-    auto load_pw = [&](const float* base, int row) -> f4 { return f4_load_rsrc(base + rowoff(row), row_bytes, loff, (FDW_NT & 1) != 0); };
+    auto rowoff = [&](int row) -> unsigned { return (unsigned)min(max(row, 0), rowmax) * row_bytes; };
+    auto load_p = [&](int row) -> f4 { return f4_load_arr(rs_p, loff, rowoff(row), (FDW_NT & 4) != 0); };
+    auto load_pw = [&](__amdgpu_buffer_rsrc_t rs, int row) -> f4 { return f4_load_arr(rs, loff, rowoff(row), (FDW_NT & 1) != 0); };
 
     // rows: wave 0's centre row at march step m is s0 + m (what the global loads follow); this wave's is rk + m
     const int s0 = xa - (NS - 1) * H, b0 = s0 - H;
@@ -861,8 +895,8 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         if constexpr (j >= -LOOK) ring[j + 2 * H + LOOK] = load_p(b0 + j + 2 * H + LOOK);
         if constexpr (j >= -PF) {
             constexpr int mm = j + PF;
-            qpp[mm] = load_pw(a.pp, s0 + mm);
-            qv2[mm] = load_pw(a.v2, s0 + mm);
+            qpp[mm] = load_pw(rs_pp, s0 + mm);
+            qv2[mm] = load_pw(rs_v2, s0 + mm);
         }
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -879,11 +913,15 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         constexpr int E = (U + 2 * H) % R;                      // slot of the row entering the window this step
         const int m = mb + U;
         const int r = rk + m;
-        const int par = m & 1;
+        constexpr int par = U & 1;                               // == m & 1: R is even
         // ---- what the previous wave handed over during march step m-1 ----
+#if FDW_ABL_BITS & 128
+        const f4 nr = ring[U], ppl = ring[(U + 1) % R], v2l = ring[(U + 2) % R];
+#else
         const f4 nr = link[kp][par ^ 1][0][lane];
         const f4 ppl = link[kp][par ^ 1][1][lane];
         const f4 v2l = fifo[(m - k * SK) & (kFifoRows - 1)][lane];
+#endif
         f4 ppt, v2t;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -891,7 +929,9 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             ppt.v[e] = first ? qpp[Q].v[e] : ppl.v[e];
             v2t.v[e] = first ? qv2[Q].v[e] : v2l.v[e];
         }
+#if !(FDW_ABL_BITS & 128)
         if (first) fifo[m & (kFifoRows - 1)][lane] = qv2[Q];
+#endif
         if (wave_tap) {
             taper_row(ring[E], r + H);                          // entering row: damped once as "p" of this step
             taper_row(ppt, r);                                  // "pp": from memory once (+ once owed), from LDS once more
@@ -901,8 +941,12 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         f4 lft, rgt;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+#if FDW_ABL_BITS & 2048
+            lft.v[e] = c1.v[(e + 1) & 3]; rgt.v[e] = c1.v[(e + 2) & 3];
+#else
             lft.v[e] = __shfl_up(c1.v[e], 1, 64);
             rgt.v[e] = __shfl_down(c1.v[e], 1, 64);
+#endif
         }
         const bool rowok = (r >= a.lap_x0) && (r < a.lap_x1);
         const bool rowupd = (r >= 0) && (r < a.upd_x1);
@@ -911,12 +955,20 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             const ZPairs zp = zpairs(lft, c1, rgt);
             static_for<2>([&](auto PP) {
                 constexpr int P = decltype(PP)::value;
+#if FDW_ABL_BITS & 256
+                const v2f lap2 = zp.E[P] + zp.O[P + 2] + f4_pair(ring[U], P) + f4_pair(ring[(U + 2 * H) % R], P);
+#else
                 const v2f lap2 = laplacian_pair<H, P>(zp, [&](auto IO) { return f4_pair(ring[(U + decltype(IO)::value) % R], P); }, cpk);
+#endif
                 const v2f prod2 = (f4_pair(v2t, P) * a.dt2) * v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int e = 2 * P + q;
+#if FDW_ABL_BITS & 512
+                    const float upd = (c1.v[e] + c1.v[e] - ppt.v[e]) + (q ? prod2.y : prod2.x);
+#else
                     const float upd = leapfrog_prod(c1.v[e], ppt.v[e], q ? prod2.y : prod2.x);
+#endif
                     u.v[e] = (rowupd && mupd[e]) ? upd : ppt.v[e];
                 }
             });
@@ -928,14 +980,20 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             }
         }
         // ---- hand over to the next wave: the new row (raw) and the row leaving this window (damped once) ----
+#if !(FDW_ABL_BITS & 128)
         link[k][par][0][lane] = u;
         link[k][par][1][lane] = ring[U];
-        const unsigned so = ((r >= xa) && (r < xe) && (m < M)) ? soff : 0xFFFFFFF0u;
-        f4_store_rsrc(outp + rowoff(r), row_bytes, so, u);
+#endif
+        const unsigned so = ((r >= xa) && (r < xe) && (m < M)) ? soff : kLaneOff;
+#if FDW_ABL_BITS & 1024
+        ring[U] = u;
+#else
+        f4_store_arr(rs_out, so, rowoff(r), u);
         // ---- look-ahead loads of wave 0 into the slots this step freed ----
         ring[U] = load_p(b0 + m + R);
-        qpp[Q] = load_pw(a.pp, s0 + m + PF);
-        qv2[Q] = load_pw(a.v2, s0 + m + PF);
+        qpp[Q] = load_pw(rs_pp, s0 + m + PF);
+        qv2[Q] = load_pw(rs_v2, s0 + m + PF);
+#endif
 #if !(FDW_ABL_BITS & 64)
         __syncthreads();
 #endif
@@ -1101,8 +1159,8 @@ hipError_t launch_stepn(const Step2Args& a, int h, int mode, hipStream_t s)
     if (h != 4) return hipErrorInvalidValue;
     const dim3 grid(8 * a.nper), block(64 * kPipeSteps);
     switch (mode) {
-    case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 1, 2>), grid, block, 0, s, a); break;
-    case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, false, 0, 2>), grid, block, 0, s, a); break;
+    case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 1, FDW_PIPE_PF>), grid, block, 0, s, a); break;
+    case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, false, 0, FDW_PIPE_PF>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

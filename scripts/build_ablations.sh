@@ -9,5 +9,5 @@ for a in "$@"; do
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -std=c++17 -Iinclude -I$C $D -c $C/fdw_kernels.hip -o ablate/k$a.o &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ablate/libfdwave_a$a.so ablate/k$a.o $C/build/fdw_api.o $C/build/fdw_host.o $C/build/fdw_config.o -lm ) &
 done
-wait
+wait; rm -f ablate/*.o
 ls -la ablate/*.so
