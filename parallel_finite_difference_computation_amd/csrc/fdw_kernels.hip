@@ -257,7 +257,7 @@ template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF>
 __device__ __forceinline__ void march(const StepArgs& a, const int lane, const int zs, const int xa, const int xe)
 {
     using G = RingGeom<H, PF>;
-    constexpr int NW = G::NW, R = G::R, LOOK = G::LOOK;
+    constexpr int R = G::R, LOOK = G::LOOK;
 #if FDW_ABL_BITS & 32
     const size_t pitch = 0;   // every row aliases row 0: loads become L1 hits -> pure issue/VALU time
 #else
@@ -282,6 +282,7 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
     if (INJ == 1) inj_here = (a.inj_x >= xa) && (a.inj_x < xe) && (a.inj_z >= zs) && (a.inj_z < zs + 256);
     if (INJ == 2) inj_here = (a.inj_z >= zs) && (a.inj_z < zs + 256) && (a.inj_x < xe) && (a.inj_x + a.inj_n > xa);
     const float inj_src = (INJ == 1 && inj_here) ? sload(a.inj, 0) : 0.0f;
+    const CoefPairs<H> cpk = coef_pairs<H>(a.cx, a.cz);
 
     // per-lane column masks and damping factors
     bool mlap[4], mupd[4], znc[4], znh[4], ihit[4];
@@ -387,37 +388,40 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
             }
             // ---- z neighbours from the adjacent lanes (ds_bpermute), strip halo at the ends ----
             const f4 c = ring[(U + H) % R];
-            float W[12];
+            f4 lft, rgt;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #if FDW_ABL_BITS & 8
-                W[e] = c.v[e] + hal.v[e];
-                W[8 + e] = c.v[e] - hal.v[e];
+                lft.v[e] = c.v[e] + hal.v[e];
+                rgt.v[e] = c.v[e] - hal.v[e];
 #else
                 const float up = __shfl_up(c.v[e], 1, 64), dn = __shfl_down(c.v[e], 1, 64);
-                W[e] = lane_first ? hal.v[e] : up;
-                W[8 + e] = lane_last ? hal.v[e] : dn;
+                lft.v[e] = lane_first ? hal.v[e] : up;
+                rgt.v[e] = lane_last ? hal.v[e] : dn;
 #endif
-                W[4 + e] = c.v[e];
             }
             const bool rowok = (r >= a.lap_x0) && (r < a.lap_x1);
             f4 res, imr;
+            {
+                // packed pairs: same products and sums in the same order as laplacian_pt (see laplacian_pair)
+                const ZPairs zp = zpairs(lft, c, rgt);
+                static_for<2>([&](auto PP) {
+                    constexpr int P = decltype(PP)::value;
+                    v2f lap2 = laplacian_pair<H, P>(zp, [&](auto IO) { return f4_pair(ring[(U + decltype(IO)::value) % R], P); }, cpk);
+                    if (zedge || xedge) lap2 = v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
+                    if constexpr (LAPONLY) {
+                        res.v[2 * P] = lap2.x;
+                        res.v[2 * P + 1] = lap2.y;
+                    } else {
+                        const v2f prod2 = (f4_pair(qv2[Q], P) * a.dt2) * lap2;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float col[NW];
-#pragma unroll
-                for (int io = 0; io < NW; ++io) col[io] = ring[(U + io) % R].v[e];
-                float lap = laplacian_pt<H>(W, e, col, a.cx, a.cz);
-                if (zedge || xedge) lap = (rowok && mlap[e]) ? lap : 0.0f;
-                float out;
-                if constexpr (LAPONLY) {
-                    out = lap;
-                } else {
-                    const float upd = leapfrog_pt(c.v[e], ppt.v[e], qv2[Q].v[e], a.dt2, lap);
-                    out = upd;
-                    if (zedge) out = mupd[e] ? upd : ppt.v[e];
-                }
-                res.v[e] = out;
+                        for (int q = 0; q < 2; ++q) {
+                            const int e = 2 * P + q;
+                            const float upd = leapfrog_prod(c.v[e], ppt.v[e], q ? prod2.y : prod2.x);
+                            res.v[e] = zedge ? (mupd[e] ? upd : ppt.v[e]) : upd;
+                        }
+                    }
+                });
             }
             if constexpr (INJ != 0) {
                 if (inj_here) {   // wave-uniform, rare
