@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--size", type=int, default=8192)
     ap.add_argument("--ksteps", type=int, default=0, help="time steps per halo exchange (N > 1); 0 = auto")
+    ap.add_argument("--pipe", choices=("auto", "on", "off"), default="auto",
+                    help="N > 1: four-steps-per-pass wave-pipeline kernel inside the slabs (auto = where the library would pick it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU rehearsals)")
@@ -108,6 +110,14 @@ def main():
         # Redundant ghost work is h*(k-1)/2 rows per side per step (5.9 % of a 1024-row slab at k = 16).
         t_step_us = (n / world) * n / 350e9 * 1e6
         args.ksteps = int(max(2, min(16, -(-500.0 // t_step_us))))
+    use_pipe = False
+    if world > 1 and args.pipe != "off":
+        # decide on the slab size every rank has in common (all ranks must take the same path): rows of the thinnest slab
+        probe = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank, slab=(0, n // world))
+        use_pipe = args.pipe == "on" or probe.steps_per_pass() == 4
+        del probe
+        if use_pipe:
+            args.ksteps = max(4, min(16, 4 * -(-args.ksteps // 4)))      # whole passes of four steps
     geom = SlabGeometry(rank, world, n, ORDER // 2, args.ksteps if world > 1 else 1)
     ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank,
                    slab=(geom.x_off, geom.nxl) if world > 1 else None)
@@ -171,7 +181,8 @@ def main():
                 g.manual_seed(seed)
                 full_rows = 1e-3 * torch.randn((n, 64), device=dev, generator=g)      # cheap, decomposition-independent pattern
                 f_[:, :n] = full_rows[geom.x_off:geom.x_off + geom.nxl].repeat(1, n // 64)
-        fw = SlabForward(geom, HipSlabStepper(ctx), (a, b), v2, srce, sx, sz, overlap=not args.no_overlap)
+        fields = (a, b) + ((torch.zeros_like(a), torch.zeros_like(a)) if use_pipe else ())
+        fw = SlabForward(geom, HipSlabStepper(ctx), fields, v2, srce, sx, sz, overlap=not args.no_overlap, pipe_ctx=ctx if use_pipe else None)
         fw.run(W)
         fw.synchronize()       # also forces torch's lazy creation of both streams outside the timed region
         sync_all()
@@ -235,7 +246,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (seeded noise wavefield)" if args.init == "noise" else " (field at rest + Ricker source)"),
             "config": {"workload": f"2D 8th-order acoustic stencil, fused forward step (taper+Laplacian+leap-frog+source), "
                                    f"{n}x{n} fp32 extended grid, nxb=nzb={NB}, {K} steps"
-                                   + (f", x-slab decomposition over {world} GPUs, {args.ksteps} steps per halo exchange" if world > 1 else ""),
+                                   + (f", x-slab decomposition over {world} GPUs, {args.ksteps} steps per halo exchange" + (", four steps per pass inside the slabs" if use_pipe else "") if world > 1 else ""),
                        "grid": [n, n], "order": ORDER, "parallelism": f"slab{world}" if world > 1 else "single"},
             "result_finite_nonzero": finite,
         }

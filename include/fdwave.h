@@ -125,6 +125,11 @@ int fdw_shot(fdw_ctx *ctx, const float *v2, int sx, int sz, int gz, const float 
  * fdw_dev_steps2  nsteps iterations over FOUR rotating buffers, in pairs through fdw_dev_step2 (odd remainder:
  *                 one-step kernel).  ip and ipp index the reference's (d_p, d_pp) before the first swap on entry
  *                 and after the loop on return.
+ * fdw_dev_step4   FOUR forward iterations in one pass of the wave-pipeline kernel (order 8, fields < 2 GiB): d_p = u^n,
+ *                 d_pp = u^{n-1} -> d_out1 = u^{n+3}, d_out2 = u^{n+4} on local rows [r0, r1) and, optionally, [r0b, r1b)
+ *                 (r1 < 0: every row the reference time-steps); rows within 16 of a range end are read from d_p / d_pp, so
+ *                 a slab driver shrinks the range by 16 rows per pass between two halo exchanges (decomp.py).
+ *                 d_srce_it -> srce[it .. it+3]; xchunk 0 = automatic.  Bit-identical to four fdw_dev_step calls.
  * fdw_dev_steps_shrink  like fdw_dev_steps for one slab of a decomposed grid between two halo exchanges:
  *                 step j = j0.. of the cycle updates rows [h*j, nxl - h*j) on the sides that have a
  *                 neighbour (shrink_lo / shrink_hi), see decomp.py.
@@ -143,6 +148,8 @@ int fdw_dev_steps_shrink(fdw_ctx *ctx, float *d_p, float *d_pp, const float *d_v
                          int it0, int nsteps, int first_pp_twice, int j0, int shrink_lo, int shrink_hi, void *stream);
 int fdw_dev_step2(fdw_ctx *ctx, const float *d_p, const float *d_pp, const float *d_v2, float *d_out1, float *d_out2, int pp_twice,
                   const float *d_srce_it, int sx, int sz, void *stream);
+int fdw_dev_step4(fdw_ctx *ctx, const float *d_p, const float *d_pp, const float *d_v2, float *d_out1, float *d_out2, int pp_twice,
+                  const float *d_srce_it, int sx, int sz, int r0, int r1, int r0b, int r1b, int xchunk, void *stream);
 int fdw_dev_steps2(fdw_ctx *ctx, float *const *d_buf, const float *d_v2, const float *d_srce, int sx, int sz, int it0, int nsteps,
                    int first_pp_twice, int *ip, int *ipp, void *stream);
 int fdw_dev_taper_finalize(fdw_ctx *ctx, float *d_f, void *stream);

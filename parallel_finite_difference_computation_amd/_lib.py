@@ -48,6 +48,7 @@ SIGNATURES = [
     ("fdw_dev_steps", C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     ("fdw_dev_steps_shrink", C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 8 + [vp]),
     ("fdw_dev_step2", C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
+    ("fdw_dev_step4", C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp] + [C.c_int] * 7 + [vp]),
     ("fdw_dev_steps2", C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]),
     ("fdw_dev_taper_finalize", C.c_int, [vp, vp, vp]),
     ("fdw_dev_laplacian", C.c_int, [vp, vp, vp, vp]),

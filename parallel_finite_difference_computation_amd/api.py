@@ -172,6 +172,10 @@ class FDWave:
         """Two forward iterations in one pass (temporal blocking); d_p is the NEWEST field."""
         check(lib().fdw_dev_step2(self._h, d_p, d_pp, d_v2, d_out1, d_out2, int(pp_twice), d_srce_it, sx, sz, stream))
 
+    def dev_step4(self, d_p, d_pp, d_v2, d_out1, d_out2, pp_twice=True, d_srce_it=None, sx=-1, sz=0, r0=0, r1=-1, r0b=0, r1b=0, xchunk=0, stream=None):
+        """Four forward iterations in one pass (wave pipeline) on local rows [r0, r1) (+ [r0b, r1b)); r1 < 0 = all rows."""
+        check(lib().fdw_dev_step4(self._h, d_p, d_pp, d_v2, d_out1, d_out2, int(pp_twice), d_srce_it, sx, sz, r0, r1, r0b, r1b, xchunk, stream))
+
     def dev_steps2(self, bufs, d_v2, d_srce, sx, sz, it0, nsteps, first_pp_twice=False, ip=0, ipp=1, stream=None):
         """nsteps iterations over four rotating device buffers (pairs via the two-step kernel).
         Returns the indices (ip, ipp) of the reference's (d_p, d_pp) after the loop."""

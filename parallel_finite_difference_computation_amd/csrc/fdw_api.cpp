@@ -491,8 +491,11 @@ static bool pipe_pays(const fdw_ctx* c)
 
 // FWD: d_inj -> kPipeSteps source samples srce[it .. it+kPipeSteps-1]; PLAIN: no taper, no injection.
 // d_out1 = u^{n+kPipeSteps-1}, d_out2 = u^{n+kPipeSteps}.
+struct RowRanges {      // rows the pass produces: [r0, r1) and optionally [r0b, r1b); r1 < 0 = all rows the reference time-steps
+    int r0 = 0, r1 = -1, r0b = 0, r1b = 0, xchunk = 0;
+};
 static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp, const float* d_v2, float* d_out1, float* d_out2, int pp_twice,
-                      const float* d_inj, int inj_x_global, int inj_z, hipStream_t s)
+                      const float* d_inj, int inj_x_global, int inj_z, hipStream_t s, const RowRanges& rr = RowRanges{})
 {
     if (c->h != kMaxFastHalfOrder) return fail(FDW_EINVAL, "stepn: the pipelined kernel is built for order 8 only");
     if (mode != FDW_MODE_FWD && mode != FDW_MODE_PLAIN) return fail(FDW_EINVAL, "stepn: FWD or PLAIN only");
@@ -503,7 +506,11 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
     a.p = d_p; a.pp = d_pp; a.v2 = d_v2; a.out1 = d_out1; a.out2 = d_out2;
     a.taperz = c->d_taperz; a.txfac = c->d_txfac; a.inj = d_inj;
     a.pitch = c->pitch; a.nxl = c->nxl;
-    a.r0 = 0; a.r1 = c->upd_x1;
+    const bool whole = rr.r1 < 0;
+    if (!whole && (rr.r0 < 0 || rr.r1 > c->nxl || rr.r0b < 0 || rr.r1b > c->nxl || (rr.r1b > rr.r0b && rr.r0b < rr.r1)))
+        return fail(FDW_EINVAL, "stepn: row ranges [%d,%d) [%d,%d) outside the slab or overlapping", rr.r0, rr.r1, rr.r0b, rr.r1b);
+    a.r0 = whole ? 0 : rr.r0; a.r1 = std::min(whole ? c->upd_x1 : rr.r1, c->upd_x1);
+    a.r0b = whole ? 0 : rr.r0b; a.r1b = whole ? 0 : std::min(rr.r1b, c->upd_x1);
     a.lap_x0 = c->lap_x0; a.lap_x1 = c->lap_x1; a.lap_z0 = c->lap_z0; a.lap_z1 = c->lap_z1;
     a.upd_x1 = c->upd_x1; a.upd_z1 = c->upd_z1;
     a.ztap = c->ztap; a.tz_x1 = c->tz_x1; a.xt_lo = c->xt_lo; a.xt_hi = c->xt_hi;
@@ -520,22 +527,24 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
     const int ncells = c->pitch / 4, own = 64 - 2 * kPipeSteps;
     a.nstrip = (ncells + own - 1) / own;
     a.nzblk = a.nstrip;
-    const int rows = a.r1 - a.r0;
+    const int rows_a = std::max(a.r1 - a.r0, 0), rows_b = std::max(a.r1b - a.r0b, 0), rows = rows_a + rows_b;
     if (rows <= 0) return FDW_OK;
     // whole ring turns: xchunk + (NS-1)(2H+1) = 10k  ->  xchunk = 10k - 27 (13, 23, ... 83, 93, ...)
     const long strip_rows = (long)rows * a.nstrip;
     // measured: 16384^2 579 Gpt/s at 253 (560 at 173); 8192^2 566 at 173 (509 at 83, 553 at 253); 4096^2 452 at 83 (382 at 43, 388 at 173);
     // 1056x8192 371 at 43 (355 at 63, 340 at 33)
     int xchunk = c->xchunk2 > 0 ? c->xchunk2 : (strip_rows >= 1000000 ? 253 : (strip_rows >= 250000 ? 173 : (strip_rows >= 60000 ? 83 : 43)));
+    if (rr.xchunk > 0) xchunk = rr.xchunk;
     a.xchunk = xchunk;
-    const int chunks = (rows + xchunk - 1) / xchunk;
+    a.chunks_a = (rows_a + xchunk - 1) / xchunk;
+    const int chunks = a.chunks_a + (rows_b + xchunk - 1) / xchunk;
     a.nblk = a.nstrip * chunks;
     a.nper = (a.nblk + 7) / 8;
     hipError_t e = launch_stepn(a, c->h, mode, s);
     if (e != hipSuccess) return fail(FDW_EHIP, "stepn launch failed: %s", hipGetErrorString(e));
     // rows the reference never time-steps swap roles every step: after an even number of steps out1 carries pp's rows, out2 p's
     static_assert(kPipeSteps % 2 == 0, "static-row bookkeeping assumes an even number of steps per pass");
-    if (c->upd_x1 < c->nxl) {
+    if (c->upd_x1 < c->nxl && (whole || rr.r1 >= c->upd_x1 || rr.r1b >= c->upd_x1)) {
         const size_t off = (size_t)c->upd_x1 * c->pitch, n = (size_t)(c->nxl - c->upd_x1) * c->pitch * sizeof(float);
         HIP_TRY(hipMemcpyAsync(d_out1 + off, d_pp + off, n, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(d_out2 + off, d_p + off, n, hipMemcpyDeviceToDevice, s));
@@ -551,6 +560,18 @@ extern "C" int fdw_dev_step2(fdw_ctx* c, const float* d_p, const float* d_pp, co
 {
     if (!c) return fail(FDW_EINVAL, "ctx is NULL");
     return step2_impl(c, FDW_MODE_FWD, d_p, d_pp, d_v2, d_out1, d_out2, pp_twice, d_srce_it, d_srce_it ? sx : -1, sz, Step2Extra{}, pick_stream(c, stream));
+}
+
+// kPipeSteps (4) forward iterations in one pass of the wave-pipeline kernel on the given row ranges of a slab
+extern "C" int fdw_dev_step4(fdw_ctx* c, const float* d_p, const float* d_pp, const float* d_v2, float* d_out1, float* d_out2, int pp_twice,
+                             const float* d_srce_it, int sx, int sz, int r0, int r1, int r0b, int r1b, int xchunk, void* stream)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    if (c->h != kMaxFastHalfOrder || (size_t)c->nxl * c->pitch * sizeof(float) >= (1ull << 31))
+        return fail(FDW_EINVAL, "step4: needs order 8 and fields below 2 GiB");
+    RowRanges rr;
+    rr.r0 = r0; rr.r1 = r1; rr.r0b = r0b; rr.r1b = r1b; rr.xchunk = xchunk;
+    return stepn_impl(c, FDW_MODE_FWD, d_p, d_pp, d_v2, d_out1, d_out2, pp_twice, d_srce_it, d_srce_it ? sx : -1, sz, pick_stream(c, stream), rr);
 }
 
 // nsteps reference iterations (R:259-267) over four rotating buffers: pairs of steps through the two-step

@@ -56,6 +56,7 @@ struct Step2Args {
     float* img;            // RECV: image accumulator on the extended grid (in place, owned cells only)
     int pitch, nxl;
     int r0, r1;            // rows whose u^{n+1}, u^{n+2} this launch produces
+    int r0b, r1b, chunks_a; // pipeline kernel only: optional second row range (chunks >= chunks_a walk [r0b, r1b))
     int lap_x0, lap_x1, lap_z0, lap_z1;
     int upd_x1, upd_z1;
     int ztap, tz_x1, xt_lo, xt_hi;

@@ -1017,8 +1017,9 @@ __global__ __launch_bounds__(64 * NS, 4) void fdw_stepn_kernel(const Step2Args a
     if (L >= a.nblk) return;                    // whole workgroups only: every barrier below is reached by all NS waves
     const int zb = L % a.nstrip;
     const int xb = L / a.nstrip;
-    const int xa = a.r0 + xb * a.xchunk;
-    const int xe = min(xa + a.xchunk, a.r1);
+    const bool second = xb >= a.chunks_a;       // two row ranges in one launch (the two boundary strips of a slab)
+    const int xa = second ? a.r0b + (xb - a.chunks_a) * a.xchunk : a.r0 + xb * a.xchunk;
+    const int xe = min(xa + a.xchunk, second ? a.r1b : a.r1);
     if (xa >= xe) return;
     __shared__ f4 link[NS][2][2][64];           // [producer wave][parity of m][0 new row | 1 row leaving the window][lane]
     __shared__ f4 fifo[kFifoRows][64];

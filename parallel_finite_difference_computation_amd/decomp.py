@@ -95,16 +95,23 @@ class HipSlabStepper:
 class SlabForward:
     """fd_forward's loop (fd-code.cu:259-267) on one slab of a decomposed grid."""
 
-    def __init__(self, geom, stepper, fields, v2, srce=None, sx=-1, sz=0, group=None, overlap=True):
+    PIPE = 4          # time steps per pass of the wave-pipeline kernel (fdw_dev_step4)
+
+    def __init__(self, geom, stepper, fields, v2, srce=None, sx=-1, sz=0, group=None, overlap=True, pipe_ctx=None):
+        """fields: two [nxl][pitch] tensors whose roles swap every step, or FOUR when `pipe_ctx` (the slab's FDWave
+        context) is given: full cycles then go four steps per pass through the wave-pipeline kernel, out of place over the
+        four rotating buffers (needs ksteps % 4 == 0 and order 8)."""
         self.g, self.stepper = geom, stepper
-        self.a, self.b = fields            # two [nxl][pitch] tensors: roles swap every step
+        self.bufs = list(fields)
+        self.a, self.b = self.bufs[0], self.bufs[1]
+        self.pipe_ctx = pipe_ctx if (pipe_ctx is not None and len(self.bufs) == 4 and geom.ksteps % self.PIPE == 0 and geom.h == 4) else None
         self.v2, self.srce, self.sx, self.sz = v2, srce, sx, sz
         self.group = group
         self.cuda = self.a.is_cuda
         self.overlap = overlap
         self.it = 0
-        self.d_p, self.d_pp = self.a, self.b
-        self._ops = None
+        self.d_p, self.d_pp = self.a, self.b       # the reference's (d_p, d_pp) BEFORE its swap: d_pp is the newest field
+        self._ops = {}
         self.fresh = False          # ghosts of both fields are up to date
         if geom.world > 1 and (geom.o1 - geom.o0) < 2 * geom.G:
             self.overlap = False    # strips would collide: fall back to exchange-then-compute
@@ -114,10 +121,12 @@ class SlabForward:
 
     # ---- halo exchange ------------------------------------------------------------------------
     def _exchange_ops(self):
-        """P2P descriptors for both time levels, built once (the views alias fixed memory)."""
-        if self._ops is None:
-            g, ops = self.g, []
-            for f in (self.a, self.b):
+        """P2P descriptors for both time levels of the current pair, built once per buffer (the views alias fixed memory)."""
+        g, out = self.g, []
+        for f in (self.d_p, self.d_pp):          # by ROLE: every rank is in the same state, so the message order matches
+            key = f.data_ptr()
+            if key not in self._ops:
+                ops = []
                 if g.has_lo:
                     s0, s1 = g.send_lo()
                     r0, r1 = g.recv_lo()
@@ -128,8 +137,9 @@ class SlabForward:
                     r0, r1 = g.recv_hi()
                     ops.append(dist.P2POp(dist.isend, f[s0:s1], g.rank + 1, group=self.group))
                     ops.append(dist.P2POp(dist.irecv, f[r0:r1], g.rank + 1, group=self.group))
-            self._ops = ops
-        return self._ops
+                self._ops[key] = ops
+            out += self._ops[key]
+        return out
 
     def exchange(self, wait_compute=True):
         """Refresh the ghost rows of both fields.  On GPU the transfer runs on the comm stream: it
@@ -167,6 +177,9 @@ class SlabForward:
         slabs in lockstep on one GPU with in-process copies at the yields."""
         g = self.g
         yield "pre"
+        if self.pipe_ctx is not None and kk == g.ksteps:
+            yield from self._pipe_cycle(more_after, stream)
+            return
         split_last = self.overlap and g.world > 1 and kk == g.ksteps and more_after
         nbulk = kk - 1 if split_last else kk
         j_next = 1
@@ -192,6 +205,37 @@ class SlabForward:
             else:
                 self._step(r0, r1, stream)
             self.it += 1
+
+    def _pipe_cycle(self, more_after, stream):
+        """A full cycle, four steps per pass (fdw_dev_step4).  Pass j = 1..ksteps/4 produces the rows still valid on the
+        interior sides, [16j, nxl - 16j); the last pass does the two strips the neighbours need first (one launch, short
+        chunks), lets the exchange of the next cycle start ("mid") and then does the interior beside the transfer."""
+        g, ctx, P = self.g, self.pipe_ctx, self.PIPE
+        passes = g.ksteps // P
+        split_last = self.overlap and g.world > 1 and more_after and (g.o1 - g.o0) >= 2 * g.G + 16
+        v2p = self.v2.data_ptr()
+        for j in range(1, passes + 1):
+            spare = [b for b in self.bufs if b is not self.d_p and b is not self.d_pp]
+            out1, out2 = spare[0], spare[1]
+            p_in, pp_in = self.d_pp, self.d_p                    # the kernel's p is the newest field (the reference's d_p after its swap)
+            lo = P * g.h * j if g.has_lo else 0
+            hi = g.nxl - (P * g.h * j if g.has_hi else 0)
+            srce_it = self.srce.data_ptr() + 4 * self.it if self.srce is not None else None
+            common = dict(pp_twice=self.it > 0, d_srce_it=srce_it, sx=self.sx if self.srce is not None else -1, sz=self.sz, stream=stream)
+            args = (p_in.data_ptr(), pp_in.data_ptr(), v2p, out1.data_ptr(), out2.data_ptr())
+            if j == passes and split_last:
+                ra = (lo, lo + g.G) if g.has_lo else (0, 0)
+                rb = (hi - g.G, hi) if g.has_hi else (0, 0)
+                if not g.has_lo:
+                    ra, rb = rb, (0, 0)
+                ctx.dev_step4(*args, r0=ra[0], r1=ra[1], r0b=rb[0], r1b=rb[1], xchunk=23, **common)
+                self.d_p, self.d_pp = out1, out2                 # what the exchange started at "mid" sends and fills
+                yield "mid"
+                ctx.dev_step4(*args, r0=lo + g.G if g.has_lo else lo, r1=hi - g.G if g.has_hi else hi, **common)
+            else:
+                ctx.dev_step4(*args, r0=lo, r1=hi, **common)
+                self.d_p, self.d_pp = out1, out2
+            self.it += P
 
     def run(self, nsteps):
         """nsteps forward iterations.  Cycle = exchange, then ksteps steps on shrinking row ranges.

@@ -221,10 +221,13 @@ def test_reference_signature_compat_library():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks,opts", [(2, ["--ksteps", "4"]), (3, ["--ksteps", "0", "--steps", "25"])])
+@pytest.mark.parametrize("ranks,opts", [(2, ["--ksteps", "4"]), (3, ["--ksteps", "0", "--steps", "25"]),
+                                        (2, ["--ksteps", "8", "--pipe", "on"]), (3, ["--ksteps", "4", "--pipe", "on", "--steps", "26"])],
+                         ids=["2ranks-k4", "3ranks-auto-odd", "2ranks-pipeline-k8", "3ranks-pipeline-k4-leftover"])
 def test_multi_process_bench_rehearsal_on_one_gpu(ranks, opts, tmp_path):
     """bench.py's N > 1 path end to end: torch.distributed.run, one process per slab, real HIP kernels, overlapped deep-halo
-    exchange -- with the gloo backend so that all ranks can share this box's single GPU (RCCL refuses duplicate devices).
+    exchange (one-step kernels, and four steps per pass through the wave-pipeline kernel on four rotating buffers) -- with the
+    gloo backend so that all ranks can share this box's single GPU (RCCL refuses duplicate devices).
     --check gathers the slabs and compares them bitwise with a single-domain run."""
     import socket
     import sys
