@@ -115,9 +115,11 @@ class SlabForward:
         self.fresh = False          # ghosts of both fields are up to date
         if geom.world > 1 and (geom.o1 - geom.o0) < 2 * geom.G:
             self.overlap = False    # strips would collide: fall back to exchange-then-compute
+        self._send_after = None     # stream whose queued work the next exchange has to wait for (default: compute)
         if self.cuda:
             self.compute = torch.cuda.Stream()
             self.comm = torch.cuda.Stream()
+            self.side = torch.cuda.Stream() if self.pipe_ctx is not None else None   # boundary strips of a split pipeline pass
 
     # ---- halo exchange ------------------------------------------------------------------------
     def _exchange_ops(self):
@@ -150,7 +152,8 @@ class SlabForward:
             return
         if self.cuda:
             if wait_compute:
-                self.comm.wait_stream(self.compute)
+                self.comm.wait_stream(self._send_after if self._send_after is not None else self.compute)
+                self._send_after = None
             stream_aware = dist.get_backend(self.group) == "nccl"
             if not stream_aware:
                 # rehearsal backends (gloo stages CUDA tensors through host copies on threads/streams of its own):
@@ -228,7 +231,14 @@ class SlabForward:
                 rb = (hi - g.G, hi) if g.has_hi else (0, 0)
                 if not g.has_lo:
                     ra, rb = rb, (0, 0)
-                ctx.dev_step4(*args, r0=ra[0], r1=ra[1], r0b=rb[0], r1b=rb[1], xchunk=23, **common)
+                # the strips go to a stream of their own: their few workgroups are a latency chain that fits beside the interior launch
+                if self.cuda:
+                    self.side.wait_stream(self.compute)
+                    strips = dict(common, stream=self.side.cuda_stream)
+                    self._send_after = self.side
+                else:
+                    strips = common
+                ctx.dev_step4(*args, r0=ra[0], r1=ra[1], r0b=rb[0], r1b=rb[1], xchunk=23, **strips)
                 self.d_p, self.d_pp = out1, out2                 # what the exchange started at "mid" sends and fills
                 yield "mid"
                 ctx.dev_step4(*args, r0=lo + g.G if g.has_lo else lo, r1=hi - g.G if g.has_hi else hi, **common)
@@ -264,6 +274,8 @@ class SlabForward:
         if self.cuda:
             self.compute.synchronize()
             self.comm.synchronize()
+            if self.side is not None:
+                self.side.synchronize()
 
     def owned(self, f):
         """The owned rows of a local field (drops ghosts)."""
