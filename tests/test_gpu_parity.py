@@ -486,3 +486,48 @@ def test_source_position_sweep_two_step():
                 oP, oPP = orc.forward(d["v2"], sx, sz, srce)
                 assert_bit_equal(PP, oPP, f"PP mode {mode} source at ({sx},{sz})")
                 assert_bit_equal(P, oP, f"P mode {mode} source at ({sx},{sz})")
+
+
+def test_dev_step4_row_ranges_vs_oracle():
+    """fdw_dev_step4 (four steps per pass) restricted to one and to two row ranges: inside the ranges the four-step result of the
+    oracle, bit for bit; outside them the output buffers are not touched; bad ranges are refused."""
+    import torch
+    d = make_deck(180, 500, 12, 14, 8, seed=21, compat=False)
+    nxe, nze = d["nxe"], d["nze"]
+    srce_h = O.ricker_wavelet(8, d["dt"], 30.0)
+    p0, pp0 = random_fields(d, seed=5, amp=0.1)
+    dev = torch.device("cuda:0")
+    ctx, orc = mk(d), mko(d)
+    oP, oPP = orc.forward(d["v2"], d["sx"], d["sz"], srce_h, p0, pp0, nsteps=4)      # oPP = u^{n+4} (newest), oP = u^{n+3}
+    def dev_field(h):
+        t = torch.zeros((nxe, ctx.pitch), device=dev)
+        t[:, :nze] = torch.from_numpy(h).to(dev)
+        return t
+    srce = torch.from_numpy(srce_h).to(dev)
+    v2 = dev_field(d["v2"])
+    # forward()'s convention: p0 = reference d_p before the first swap, pp0 = d_pp (the newest) -> the kernel's p is pp0
+    newest, older = dev_field(pp0), dev_field(p0)
+    for ranges in (dict(r0=0, r1=-1), dict(r0=40, r1=97), dict(r0=16, r1=50, r0b=120, r1b=164, xchunk=13), dict(r0=0, r1=33, r0b=150, r1b=180, xchunk=23)):
+        out1 = torch.full((nxe, ctx.pitch), 7.0, device=dev)
+        out2 = torch.full((nxe, ctx.pitch), -7.0, device=dev)
+        ctx.dev_step4(newest.data_ptr(), older.data_ptr(), v2.data_ptr(), out1.data_ptr(), out2.data_ptr(), pp_twice=False,
+                      d_srce_it=srce.data_ptr(), sx=d["sx"], sz=d["sz"], **ranges)
+        ctx.dev_taper_finalize(out1.data_ptr())     # as fdw_forward does for the field it returns as P (the reference downloads the damped d_p, R:285)
+        torch.cuda.synchronize()
+        rows = np.zeros(nxe, bool)
+        if ranges["r1"] < 0:
+            rows[:] = True
+        else:
+            rows[ranges["r0"]:ranges["r1"]] = True
+            rows[ranges.get("r0b", 0):ranges.get("r1b", 0)] = True
+        h1, h2 = out1[:, :nze].cpu().numpy(), out2[:, :nze].cpu().numpy()
+        assert_bit_equal(h2[rows], oPP[rows], f"u^(n+4) on {ranges}")
+        assert_bit_equal(h1[rows], oP[rows], f"u^(n+3) on {ranges}")
+        assert (h2[~rows] == -7.0).all() and (h1[~rows][:, d["nzb"]:] == 7.0).all(), f"rows outside {ranges} were written"
+    with pytest.raises(F.FdwError):
+        ctx.dev_step4(newest.data_ptr(), older.data_ptr(), v2.data_ptr(), newest.data_ptr(), older.data_ptr())          # aliasing
+    with pytest.raises(F.FdwError):
+        ctx.dev_step4(newest.data_ptr(), older.data_ptr(), v2.data_ptr(), out1.data_ptr(), out2.data_ptr(), r0=0, r1=nxe + 1)
+    with pytest.raises(F.FdwError):
+        ctx.dev_step4(newest.data_ptr(), older.data_ptr(), v2.data_ptr(), out1.data_ptr(), out2.data_ptr(), r0=50, r1=90, r0b=80, r1b=120)
+    assert ctx.steps_per_pass() == 1 and mk(make_deck(1200, 8192, 16, 16, 4, seed=1, compat=False)).steps_per_pass() == 4
