@@ -55,7 +55,12 @@ typedef struct fdw_params {
     int coef_cxx;   /* 1: generic-order weights with float cosf/powf as in the stencil program (S:184-216
                        is compiled as C++); 0: double libm as in libsource.a (F:160-192).  Irrelevant
                        for order 2/4/6/8 */
+    int dialect;    /* 0 (FDW_DIALECT_RTM): the CUDA programs' arithmetic and one-sided taper (everything above);
+                       1 (FDW_DIALECT_MOD): the CPU-serial sibling's forward modelling -- dpct_gpu_rtm_domain_division/src:
+                       fd_step's single accumulator (timestep/fd.c:24-46), four-sided taper_apply with taper = exp(-(F*(nb-i))^2)
+                       (boundary/taper.c:26-66), whole-grid update; order <= 8; only fdw_model_shot and the host helpers use it */
 } fdw_params;
+enum { FDW_DIALECT_RTM = 0, FDW_DIALECT_MOD = 1 };
 
 /* A slab of the global grid owned by one device (domain decomposition along x, the slow axis).
  * The reference has no multi-GPU path; slab 0..nxe is the single-GPU case. */
@@ -154,6 +159,19 @@ int fdw_dev_steps2(fdw_ctx *ctx, float *const *d_buf, const float *d_v2, const f
                    int first_pp_twice, int *ip, int *ipp, void *stream);
 int fdw_dev_taper_finalize(fdw_ctx *ctx, float *d_f, void *stream);
 int fdw_dev_laplacian(fdw_ctx *ctx, const float *d_p, float *d_lap, void *stream);
+
+/* ---- forward-modelling producer -------------------------------------------------------
+ * fdw_model_shot  one shot of mod_main's loop (dpct_gpu_rtm_domain_division/src/mod_main.cpp:140-174) on a context created with
+ *                 dialect = FDW_DIALECT_MOD: P = PP = 0; nt x { fd_step; ptsrc (7x7 Gaussian around (sx, sz), source/ptsrc.c:12-58);
+ *                 taper_apply(PP); taper_apply(P); data[ix][it] = P[ix+nxb][gz] }.  vel2[nxe][nze] is the extended squared
+ *                 velocity (after fdw_mod_extendvel), srce[nt], data[nx][nt].  Device resident, one launch per step.
+ * fdw_mod_extendvel       taper.c:7-23: replicate the edge values outwards (in place, [nxe][nze])
+ * fdw_mod_ricker_wavelet  ptsrc.c:88-99: Ricker delayed by 1/fpeak, zero after 2/fpeak
+ * fdw_mod_taper_tables    taper.c:26-44 */
+int fdw_model_shot(fdw_ctx *ctx, const float *vel2, int sx, int sz, int gz, const float *srce, int nt, float *data);
+void fdw_mod_extendvel(int nx, int nz, int nxb, int nzb, float *vel);
+void fdw_mod_ricker_wavelet(int nt, float dt, float fpeak, float *srce);
+void fdw_mod_taper_tables(int nxb, int nzb, float fac, float *taper_x, float *taper_z);
 
 /* host <-> pitched device copies (dense [rows][nze] on the host side), synchronous */
 int fdw_upload_field(fdw_ctx *ctx, float *d_dst, const float *h_src);

@@ -1,0 +1,135 @@
+/*
+ * fdw_oracle_mod.c -- TEST INFRASTRUCTURE ONLY (same rules as fdw_oracle.c).  CPU restatement of the
+ * forward-modelling producer of the reference's CPU-serial sibling: the program
+ * that synthesises the `datfile` an RTM run consumes.
+ *
+ * Citations: M  = dpct_gpu_rtm_domain_division/src/mod_main.cpp
+ *            FD = dpct_gpu_rtm_domain_division/src/timestep/fd.c
+ *            T  = dpct_gpu_rtm_domain_division/src/boundary/taper.c
+ *            PS = dpct_gpu_rtm_domain_division/src/source/ptsrc.c
+ * The reference builds ALL of these with g++ (their Makefiles set CC = g++ -fpermissive), so calls such as
+ * exp(float) resolve to the C++ float overloads; this file is C and spells those choices out (expf / exp).
+ *
+ * Parity pins: orc_mod_shot reproduces build/3lay_mod/dobs.bin (151 traces x 1001 samples) BIT-EXACTLY from
+ * build/3lay_mod/3layer_151x151.bin + input.dat (tests/test_oracle_golden.py); the individual passes are
+ * bit-exact against oracle/_ref/libref_dd.so = FD, T, PS compiled unmodified with the reference's own flags.
+ *
+ * Build: gcc -O2 -ffp-contract=off (the reference's g++ -O3 for x86-64 has no FMA to contract either).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MOD_PI (3.141592653589793) /* cwp.h PI */
+
+/* FD:54-92 calc_coefs: table orders 2..8 are the same rationals as the CUDA path's; other orders (makeo2 as C++:
+ * cos(float) and pow(float,float) are the float overloads) are not needed by any deck and are left to orc_calc_coefs(cxx=1). */
+void orc_calc_coefs(int order, int cxx, float *coef);
+
+/* T:26-44: taper[i] = exp(-pow(F*(nb-i), 2)); F*(nb-i) is a float product, pow(float,int) promotes to double in C++11 */
+void orc_mod_taper_tables(int nxb, int nzb, float F, float *taperx, float *taperz)
+{
+    for (int i = 0; i < nxb; i++) taperx[i] = exp(-pow((double)(F * (nxb - i)), 2));
+    for (int i = 0; i < nzb; i++) taperz[i] = exp(-pow((double)(F * (nzb - i)), 2));
+}
+
+/* T:7-23: replicate the edge values of the (squared) velocity outwards */
+void orc_mod_extendvel(int nx, int nz, int nxb, int nzb, float *vel)
+{
+    const int rnz = nz + 2 * nzb;
+    for (int ix = 0; ix < nx; ix++) {
+        for (int iz = 0; iz < nzb; iz++) vel[(ix + nxb) * rnz + iz] = vel[(ix + nxb) * rnz + nzb];
+        for (int iz = nzb + nz; iz < nz + 2 * nzb; iz++) vel[(ix + nxb) * rnz + iz] = vel[(ix + nxb) * rnz + nz + nzb - 1];
+    }
+    for (int iz = 0; iz < nz + 2 * nzb; iz++) {
+        for (int ix = 0; ix < nxb; ix++) vel[ix * rnz + iz] = vel[nxb * rnz + iz];
+        for (int ix = nxb + nx; ix < nx + 2 * nxb; ix++) vel[ix * rnz + iz] = vel[(nx + nxb - 1) * rnz + iz];
+    }
+}
+
+/* PS:88-99 + PS:60-86: Ricker wavelet delayed by 1/fpeak and cut off after 2/fpeak */
+void orc_mod_ricker_wavelet(int nt, float dt, float peak, float *s)
+{
+    for (int it = 0; it < nt; it++) {
+        if (it * dt > 2.0 / peak) {
+            s[it] = 0.0;
+        } else {
+            const float t = it * dt - 1.0 / peak;
+            const float x = MOD_PI * peak * t;
+            const float xx = x * x;
+            s[it] = expf(-xx) * (1.0 - 2.0 * xx); /* exp(float) is the float overload under g++ */
+        }
+    }
+}
+
+/* T:46-66 taper_apply: z factors on the top and bottom strips of every row, then x factors on the left and right strips of
+ * every column */
+void orc_mod_taper_apply(float *pp, int nx, int nz, int nxb, int nzb, const float *taperx, const float *taperz)
+{
+    const int nze = nz + 2 * nzb;
+    for (int itx = 0; itx < nx + 2 * nxb; itx++) {
+        for (int itz = 0; itz < nzb; itz++) pp[itx * nze + itz] *= taperz[itz];
+        for (int itz = nzb - 1, i = 0; itz > -1; itz--, i++) pp[itx * nze + nz + nzb + i] *= taperz[itz];
+    }
+    for (int itz = 0; itz < nz + 2 * nzb; itz++) {
+        for (int itx = 0; itx < nxb; itx++) pp[itx * nze + itz] *= taperx[itx];
+        for (int itx = nxb - 1, i = 0; itx > -1; itx--, i++) pp[(nx + nxb + i) * nze + itz] *= taperx[itx];
+    }
+}
+
+/* FD:24-46 fd_step: ONE accumulator, z term then x term per tap, weights scaled per term; Laplacian only inside the
+ * order/2 frame (zero elsewhere, FD:19); update on the whole grid */
+void orc_mod_fd_step(int order, const float *coefs, float dx2inv, float dz2inv, float dt2, const float *p, float *pp, const float *v2,
+                     float *laplace, int nze, int nxe)
+{
+    const int h = order / 2;
+    float acm = 0;
+    for (int ix = h; ix < nxe - h; ix++)
+        for (int iz = h; iz < nze - h; iz++) {
+            for (int io = 0; io <= order; io++) {
+                acm += p[ix * nze + iz + io - h] * coefs[io] * dz2inv;
+                acm += p[(ix + io - h) * nze + iz] * coefs[io] * dx2inv;
+            }
+            laplace[ix * nze + iz] = acm;
+            acm = 0.0;
+        }
+    for (int ix = 0; ix < nxe; ix++)
+        for (int iz = 0; iz < nze; iz++) {
+            const int i = ix * nze + iz;
+            pp[i] = 2. * p[i] - pp[i] + v2[i] * dt2 * laplace[i];
+        }
+}
+
+/* PS:12-58 ptsrc: 7x7 Gaussian blob; exp(float) is the float overload under g++, the product and the sum are float */
+void orc_mod_ptsrc(int xs, int zs, int nx, int nz, float ts, float *s)
+{
+    const float xsn = xs, zsn = zs;
+    for (int ix = (xs - 3 > 0 ? xs - 3 : 0); ix <= (xs + 3 < nx - 1 ? xs + 3 : nx - 1); ++ix)
+        for (int iz = (zs - 3 > 0 ? zs - 3 : 0); iz <= (zs + 3 < nz - 1 ? zs + 3 : nz - 1); ++iz) {
+            const float xn = ix - xsn, zn = iz - zsn;
+            s[ix * nz + iz] += ts * expf(-xn * xn - zn * zn);
+        }
+}
+
+/* M:140-174: one shot of the modelling loop.  v2 is the extended squared velocity, data is [nx][nt]. */
+void orc_mod_shot(int order, int nx, int nz, int nxb, int nzb, int nt, float dx, float dz, float dt, float fac, const float *v2, int sx, int sz,
+                  int gz, const float *srce, float *data)
+{
+    const int nxe = nx + 2 * nxb, nze = nz + 2 * nzb;
+    const size_t ne = (size_t)nxe * nze;
+    const float dx2inv = (1. / dx) * (1. / dx), dz2inv = (1. / dz) * (1. / dz), dt2 = dt * dt; /* FD:13-15 */
+    float coefs[65];
+    orc_calc_coefs(order, 1, coefs);
+    float *taperx = (float *)malloc(sizeof(float) * (nxb > 0 ? nxb : 1)), *taperz = (float *)malloc(sizeof(float) * (nzb > 0 ? nzb : 1));
+    orc_mod_taper_tables(nxb, nzb, fac, taperx, taperz);
+    float *P = (float *)calloc(ne, sizeof(float)), *PP = (float *)calloc(ne, sizeof(float)), *lap = (float *)calloc(ne, sizeof(float));
+    for (int it = 0; it < nt; it++) {
+        orc_mod_fd_step(order, coefs, dx2inv, dz2inv, dt2, P, PP, v2, lap, nze, nxe);
+        orc_mod_ptsrc(sx, sz, nxe, nze, srce[it], PP);
+        orc_mod_taper_apply(PP, nx, nz, nxb, nzb, taperx, taperz);
+        orc_mod_taper_apply(P, nx, nz, nxb, nzb, taperx, taperz);
+        for (int ix = 0; ix < nx; ix++) data[(size_t)ix * nt + it] = P[(size_t)(ix + nxb) * nze + gz];
+        float *tmp = PP; PP = P; P = tmp;
+    }
+    free(P); free(PP); free(lap); free(taperx); free(taperz);
+}

@@ -41,6 +41,13 @@ def lib():
         L.orc_slab_step.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, f32p, f32p] + [C.c_int] * 6 + [C.c_float]
         L.orc_stencil.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f32p, f32p]
         L.orc_fused_steps.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, C.c_float, C.c_int]
+        L.orc_mod_taper_tables.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
+        L.orc_mod_extendvel.argtypes = [C.c_int] * 4 + [f32p]
+        L.orc_mod_ricker_wavelet.argtypes = [C.c_int, C.c_float, C.c_float, f32p]
+        L.orc_mod_taper_apply.argtypes = [f32p] + [C.c_int] * 4 + [f32p, f32p]
+        L.orc_mod_fd_step.argtypes = [C.c_int, f32p, C.c_float, C.c_float, C.c_float, f32p, f32p, f32p, f32p, C.c_int, C.c_int]
+        L.orc_mod_ptsrc.argtypes = [C.c_int] * 4 + [C.c_float, f32p]
+        L.orc_mod_shot.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p]
         _LIB = L
     return _LIB
 
@@ -146,3 +153,36 @@ class Oracle:
         lib().orc_fd_back(self._h, np.ascontiguousarray(v2, np.float32), np.ascontiguousarray(snap0, np.float32),
                           np.ascontiguousarray(snap1, np.float32), d_obs, gz, imloc, nsteps)
         return imloc
+
+
+# ---- forward-modelling producer of the CPU-serial sibling (oracle/fdw_oracle_mod.c) ---------------------------------
+def mod_taper_tables(nxb, nzb, fac):
+    tx, tz = np.ones(max(nxb, 1), np.float32), np.ones(max(nzb, 1), np.float32)
+    lib().orc_mod_taper_tables(nxb, nzb, fac, tx, tz)
+    return tx[:nxb], tz[:nzb]
+
+
+def mod_extendvel(vel, nx, nz, nxb, nzb):
+    vel = np.ascontiguousarray(vel, np.float32)
+    lib().orc_mod_extendvel(nx, nz, nxb, nzb, vel)
+    return vel
+
+
+def mod_ricker_wavelet(nt, dt, fpeak):
+    s = np.zeros(nt, np.float32)
+    lib().orc_mod_ricker_wavelet(nt, dt, fpeak, s)
+    return s
+
+
+def mod_shot(order, nx, nz, nxb, nzb, dx, dz, dt, fac, vel2, sx, sz, gz, srce):
+    """mod_main's loop for one shot (mod_main.cpp:140-174): data[nx][nt]."""
+    srce = np.ascontiguousarray(srce, np.float32)
+    data = np.zeros((nx, srce.size), np.float32)
+    lib().orc_mod_shot(order, nx, nz, nxb, nzb, srce.size, dx, dz, dt, fac, np.ascontiguousarray(vel2, np.float32), sx, sz, gz, srce, data)
+    return data
+
+
+def ref_dd_lib():
+    """The CPU-serial sibling's fd.c / taper.c / ptsrc.c compiled unmodified with g++ (oracle/_ref/libref_dd.so); None when not built."""
+    so = os.path.join(_HERE, "_ref", "libref_dd.so")
+    return C.CDLL(so) if os.path.exists(so) else None

@@ -24,7 +24,7 @@ class Params(C.Structure):
     """struct fdw_params (fdwave.h) == the arguments of the reference's fd_init (fd-code.cu:200)."""
     _fields_ = [("order", C.c_int), ("nxe", C.c_int), ("nze", C.c_int), ("nxb", C.c_int), ("nzb", C.c_int),
                 ("nt", C.c_int), ("dx", C.c_float), ("dz", C.c_float), ("dt", C.c_float), ("fac", C.c_float),
-                ("compat", C.c_int), ("coef_cxx", C.c_int)]
+                ("compat", C.c_int), ("coef_cxx", C.c_int), ("dialect", C.c_int)]
 
 
 class Slab(C.Structure):
@@ -51,6 +51,10 @@ SIGNATURES = [
     ("fdw_dev_step4", C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp] + [C.c_int] * 7 + [vp]),
     ("fdw_dev_steps2", C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]),
     ("fdw_dev_taper_finalize", C.c_int, [vp, vp, vp]),
+    ("fdw_model_shot", C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p]),
+    ("fdw_mod_extendvel", None, [C.c_int] * 4 + [f32p]),
+    ("fdw_mod_ricker_wavelet", None, [C.c_int, C.c_float, C.c_float, f32p]),
+    ("fdw_mod_taper_tables", None, [C.c_int, C.c_int, C.c_float, f32p, f32p]),
     ("fdw_dev_laplacian", C.c_int, [vp, vp, vp, vp]),
     ("fdw_upload_field", C.c_int, [vp, vp, f32p]),
     ("fdw_download_field", C.c_int, [vp, f32p, vp]),

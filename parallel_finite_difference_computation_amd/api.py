@@ -56,12 +56,33 @@ def extendvel_linear(vpe, nx, nz, nxb, nzb):
     return vpe
 
 
+def mod_extendvel(vel, nx, nz, nxb, nzb):
+    """taper.c:7-23 of the CPU-serial sibling: replicate the edge values outwards, in place on [nxe][nze]."""
+    vel = _f32(vel, (nx + 2 * nxb, nz + 2 * nzb))
+    lib().fdw_mod_extendvel(nx, nz, nxb, nzb, vel)
+    return vel
+
+
+def mod_ricker_wavelet(nt, dt, fpeak):
+    s = np.zeros(nt, np.float32)
+    lib().fdw_mod_ricker_wavelet(nt, dt, fpeak, s)
+    return s
+
+
+def mod_taper_tables(nxb, nzb, fac):
+    tx, tz = np.ones(max(nxb, 1), np.float32), np.ones(max(nzb, 1), np.float32)
+    lib().fdw_mod_taper_tables(nxb, nzb, fac, tx, tz)
+    return tx[:nxb], tz[:nzb]
+
+
 class FDWave:
     """One fd_init (fd-code.cu:200-224 / fd-source-code.cu:241-262) worth of state on one MI355X."""
 
     def __init__(self, order, nxe, nze, nxb=0, nzb=0, nt=0, fac=1.0, dx=1.0, dz=1.0, dt=0.0, *, compat=True,
-                 coef_cxx=False, device=0, slab=None):
-        self.params = Params(order, nxe, nze, nxb, nzb, nt, dx, dz, dt, fac, int(compat), int(coef_cxx))
+                 coef_cxx=False, device=0, slab=None, dialect=0):
+        """dialect 0: the CUDA programs (stencil_code / rtm_code); 1: the forward-modelling producer of the CPU-serial sibling
+        (mod_main: model_shot only)."""
+        self.params = Params(order, nxe, nze, nxb, nzb, nt, dx, dz, dt, fac, int(compat), int(coef_cxx), int(dialect))
         self._h = C.c_void_p()
         if slab is None:
             check(lib().fdw_create(C.byref(self.params), device, C.byref(self._h)))
@@ -153,6 +174,13 @@ class FDWave:
                              _f32(d_obs, (self.nx, self.nt)), imloc,
                              P.ctypes.data if want_fields else None, PP.ctypes.data if want_fields else None))
         return (imloc, P, PP) if want_fields else imloc
+
+    def model_shot(self, vel2, sx, sz, gz, srce):
+        """One shot of mod_main's loop (dpct_gpu_rtm_domain_division/src/mod_main.cpp:140-174): the gather data[nx][nt]."""
+        srce = _f32(srce)
+        data = np.zeros((self.nx, srce.size), np.float32)
+        check(lib().fdw_model_shot(self._h, _f32(vel2, (self.nxe, self.nze)), sx, sz, gz, srce, srce.size, data))
+        return data
 
     # ---- device-array API (raw pointers; see device.py for torch helpers) -----------------------
     def dev_step(self, mode, d_p, d_pp, d_v2, r0=0, r1=None, pp_twice=True, d_inj=None, inj_x=-1, inj_z=0,

@@ -58,8 +58,10 @@ struct fdw_ctx {
     int lap_x0 = 0, lap_x1 = 0, lap_z0 = 0, lap_z1 = 0;     // RTM modes
     int slap_x0 = 0, slap_x1 = 0, slap_z0 = 0, slap_z1 = 0; // stencil program (full interior)
     int upd_x1 = 0, upd_z1 = 0, tz_x1 = 0, xt_lo = 0, xt_hi = 0;
-    float dt2 = 0.f;
-    float cx[FDW_MAX_ORDER + 1]{}, cz[FDW_MAX_ORDER + 1]{};    // RTM weights (C libm variant unless coef_cxx)
+    float dt2 = 0.f, dx2inv = 0.f, dz2inv = 0.f;
+    float cx[FDW_MAX_ORDER + 1]{}, cz[FDW_MAX_ORDER + 1]{};    // RTM weights (C libm variant unless coef_cxx); dialect MOD: unscaled
+    float* d_rec = nullptr;     // dialect MOD: trace samples [nt][nx] of one shot
+    size_t rec_cap = 0;
     std::vector<float> taper_x, taper_z, txfac;
     // device tables
     float *d_taperz = nullptr, *d_txfac = nullptr, *d_gcx = nullptr, *d_gcz = nullptr;
@@ -135,6 +137,9 @@ static int validate(const fdw_params* p, const fdw_slab* s)
         return fail(FDW_EINVAL, "fac=%g must be in (0,1]", (double)p->fac);
     if (!(p->dx > 0.0f) || !(p->dz > 0.0f)) return fail(FDW_EINVAL, "dx, dz must be positive");
     if (p->nt < 0) return fail(FDW_EINVAL, "nt=%d is negative", p->nt);
+    if (p->dialect != FDW_DIALECT_RTM && p->dialect != FDW_DIALECT_MOD) return fail(FDW_EINVAL, "dialect=%d is unknown", p->dialect);
+    if (p->dialect == FDW_DIALECT_MOD && p->order > 2 * kMaxFastHalfOrder)
+        return fail(FDW_EINVAL, "dialect MOD is built for orders 2..%d", 2 * kMaxFastHalfOrder);
     if (s->nxl <= p->order || s->x_off < 0 || s->x_off + s->nxl > p->nxe)
         return fail(FDW_EINVAL, "slab [%d,%d) does not fit the grid (nxe=%d) or is thinner than the stencil",
                     s->x_off, s->x_off + s->nxl, p->nxe);
@@ -178,7 +183,12 @@ extern "C" int fdw_create_slab(const fdw_params* prm, const fdw_slab* slab, int 
     }
 
     // launch extents, R:185-195 (the int assignment truncates before ceil)
-    if (prm->compat) {
+    const bool mod = prm->dialect == FDW_DIALECT_MOD;
+    if (mod) {                    // fd.c:24-46 and taper.c:46-66 walk the whole array; the z table spans the whole row
+        c->xlim = prm->nxe;
+        c->zlim = prm->nze;
+        c->ztap = prm->nze;
+    } else if (prm->compat) {
         c->xlim = 8 * (prm->nxe / 8);
         c->zlim = 8 * (prm->nze / 8);
         c->ztap = 8 * (prm->nzb / 8);
@@ -210,16 +220,29 @@ extern "C" int fdw_create_slab(const fdw_params* prm, const fdw_slab* slab, int 
     const float dx2inv = (1. / prm->dx) * (1. / prm->dx);
     const float dz2inv = (1. / prm->dz) * (1. / prm->dz);
     c->dt2 = prm->dt * prm->dt;
+    c->dx2inv = dx2inv;
+    c->dz2inv = dz2inv;
     float w[FDW_MAX_ORDER + 1];
-    fdw_calc_coefs(prm->order, prm->coef_cxx, w);
+    fdw_calc_coefs(prm->order, mod ? 1 : prm->coef_cxx, w);
     for (int io = 0; io <= prm->order; io++) {
-        c->cz[io] = dz2inv * w[io];
-        c->cx[io] = dx2inv * w[io];
+        c->cz[io] = mod ? w[io] : dz2inv * w[io];      // fd.c:33-34 scales inside every term
+        c->cx[io] = mod ? w[io] : dx2inv * w[io];
     }
     c->taper_x.assign(std::max(prm->nxb, 1), 1.0f);
     c->taper_z.assign(std::max(prm->nzb, 1), 1.0f);
-    if (prm->nxb > 0) fdw_taper_tables(prm->nxb, 0, prm->fac, c->taper_x.data(), nullptr);
-    if (prm->nzb > 0) fdw_taper_tables(0, prm->nzb, prm->fac, nullptr, c->taper_z.data());
+    if (mod) {
+        fdw_mod_taper_tables(prm->nxb, prm->nzb, prm->fac, c->taper_x.data(), c->taper_z.data());
+        // taper.c:50-56 as ONE factor per column: top strip, 1.0f, mirrored bottom strip
+        std::vector<float> full(prm->nze, 1.0f);
+        for (int i = 0; i < prm->nzb; i++) {
+            full[i] = c->taper_z[i];
+            full[prm->nze - 1 - i] = c->taper_z[i];
+        }
+        c->taper_z.swap(full);
+    } else {
+        if (prm->nxb > 0) fdw_taper_tables(prm->nxb, 0, prm->fac, c->taper_x.data(), nullptr);
+        if (prm->nzb > 0) fdw_taper_tables(0, prm->nzb, prm->fac, nullptr, c->taper_z.data());
+    }
     // per-row x factor: thread i < nxb (and < xlim) scales columns i and nxe-1-i by taperx[i] (R:108-115)
     c->txfac.assign(c->nxl, 1.0f);
     for (int l = 0; l < c->nxl; l++) {
@@ -265,7 +288,7 @@ extern "C" void fdw_destroy(fdw_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     float* bufs[] = {c->d_taperz, c->d_txfac, c->d_gcx, c->d_gcz, c->fld[0], c->fld[1], c->fld[2], c->fld[3],
-                     c->fld[4], c->fld[5], c->fld[6], c->fld[7], c->d_v2, c->d_img, c->d_srce, c->d_dobs};
+                     c->fld[4], c->fld[5], c->fld[6], c->fld[7], c->d_v2, c->d_img, c->d_srce, c->d_dobs, c->d_rec};
     for (float* b : bufs)
         if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -312,13 +335,15 @@ static void fill_geometry(const fdw_ctx* c, StepArgs& a, int rows)
 
 static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const float* d_v2, int r0, int r1,
                      int pp_twice, const float* d_inj, int inj_x_global, int inj_z, const float* d_psrc, float* d_img,
-                     hipStream_t s)
+                     hipStream_t s, float* d_rec_row = nullptr, int rec_z = 0)
 {
     const bool lap = (mode == FDW_MODE_LAP);
     if (!d_p || !d_pp) return fail(FDW_EINVAL, "step: field pointer is NULL");
     if (!lap && !d_v2) return fail(FDW_EINVAL, "step: v2 is NULL");
     if (mode == FDW_MODE_RECV && (!d_psrc || !d_img || !d_inj)) return fail(FDW_EINVAL, "step: RECV needs d_inj, d_psrc and d_img");
-    if (mode < FDW_MODE_FWD || mode > FDW_MODE_LAP) return fail(FDW_EINVAL, "step: unknown mode %d", mode);
+    if (mode < FDW_MODE_FWD || mode > FDW_MODE_MOD) return fail(FDW_EINVAL, "step: unknown mode %d", mode);
+    if ((mode == FDW_MODE_MOD) != (c->prm.dialect == FDW_DIALECT_MOD))
+        return fail(FDW_ESTATE, "step: mode %d does not belong to this context's dialect %d", mode, c->prm.dialect);
     if (r0 < 0 || r1 > c->nxl || r0 > r1) return fail(FDW_EINVAL, "step: rows [%d,%d) outside the slab (%d rows)", r0, r1, c->nxl);
 
     StepArgs a{};
@@ -339,6 +364,20 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
         a.inj_x = inj_x_global - c->slab.x_off;   // may fall outside this slab: then no row matches
         if (a.inj_x >= c->upd_x1 && a.inj_x < c->nxl)
             return fail(FDW_EINVAL, "step: source row %d lies in rows the reference never time-steps (>= %d)", inj_x_global, c->xlim);
+    } else if (mode == FDW_MODE_MOD) {
+        if (d_inj) {
+            if (inj_z < 0 || inj_z >= c->prm.nze || inj_x_global < 0 || inj_x_global >= c->prm.nxe)
+                return fail(FDW_EINVAL, "step: source (%d,%d) outside the grid", inj_x_global, inj_z);
+            a.inj_x = inj_x_global - c->slab.x_off;
+        } else {
+            a.inj_x = -1000000;
+        }
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) a.gw[i][j] = expf(-(float)(i * i) - (float)(j * j));   // ptsrc.c:53 with exp(float) as g++ resolves it
+        a.dx2inv = c->dx2inv; a.dz2inv = c->dz2inv;
+        a.rec = d_rec_row; a.rec_z = rec_z;
+        a.rec_x0 = c->prm.nxb - c->slab.x_off; a.rec_n = c->nx;
+        if (d_rec_row && (rec_z < 0 || rec_z >= c->prm.nze)) return fail(FDW_EINVAL, "step: receiver depth %d outside the grid", rec_z);
     } else if (mode == FDW_MODE_RECV) {
         if (inj_z < 0 || inj_z >= c->prm.nze) return fail(FDW_EINVAL, "step: receiver depth %d outside the grid", inj_z);
         // receivers sit on interior columns nxb..nxb+nx-1 (R:126-129); clip to this slab
@@ -359,6 +398,7 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
         fill_geometry(c, a, a.r1 - a.r0);
         e = launch_step_fast(a, c->h, mode, effective_prefetch(c), s);
     } else {
+        if (mode == FDW_MODE_MOD) return fail(FDW_EINVAL, "step: the modelling dialect has no generic-order kernel");
         e = launch_step_generic(a, c->h, mode, s);
     }
     if (e != hipSuccess) return fail(FDW_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -402,7 +442,7 @@ extern "C" int fdw_dev_steps(fdw_ctx* c, float* d_p, float* d_pp, const float* d
 constexpr long kPipeAutoStripRows = 30000;
 static bool two_step_pays(const fdw_ctx* c)
 {
-    if (c->h != kMaxFastHalfOrder || c->use_generic || c->tb < 0) return false;
+    if (c->h != kMaxFastHalfOrder || c->use_generic || c->tb < 0 || c->prm.dialect != FDW_DIALECT_RTM) return false;
     if (c->tb > 0) return true;
     return (long)c->upd_x1 * ((c->pitch / 4 + 59) / 60) >= 200000;
 }
@@ -482,7 +522,7 @@ static int step2_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
 // ---- kPipeSteps time steps per pass (wave pipeline through LDS) -------------------------------------
 static bool pipe_pays(const fdw_ctx* c)
 {
-    if (c->h != kMaxFastHalfOrder || c->use_generic || c->tb < 0) return false;
+    if (c->h != kMaxFastHalfOrder || c->use_generic || c->tb < 0 || c->prm.dialect != FDW_DIALECT_RTM) return false;
     if ((size_t)c->nxl * c->pitch * sizeof(float) >= (1ull << 31)) return false;   // the kernel addresses a field through one 2 GiB buffer descriptor
     if (c->tb == kPipeSteps) return true;
     if (c->tb > 0) return false;                                   // two-step forced
@@ -907,6 +947,42 @@ extern "C" int fdw_set_tuning(fdw_ctx* c, int xchunk, int wz, int use_generic, i
     c->prefetch = prefetch;
     c->tb = two_step < 0 ? -1 : (two_step == kPipeSteps ? kPipeSteps : (two_step > 0 ? 1 : 0));   // kPipeSteps: force the wave-pipeline kernel
     c->xchunk2 = xchunk;   // the two-step kernel shares the knob (0 = its own default)
+    return FDW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward-modelling producer (dialect MOD): mod_main.cpp:140-174
+// ------------------------------------------------------------------------------------------------
+extern "C" int fdw_model_shot(fdw_ctx* c, const float* vel2, int sx, int sz, int gz, const float* srce, int nt, float* data)
+{
+    if (!c || !vel2 || !data || (!srce && nt > 0)) return fail(FDW_EINVAL, "NULL argument");
+    if (c->prm.dialect != FDW_DIALECT_MOD) return fail(FDW_ESTATE, "fdw_model_shot needs a context created with dialect = FDW_DIALECT_MOD");
+    if (!is_full_grid(c)) return fail(FDW_EINVAL, "fdw_model_shot needs a full-grid context");
+    if (nt < 0) return fail(FDW_EINVAL, "nt=%d", nt);
+    if (gz < c->prm.nzb || gz >= c->prm.nzb + c->nz)
+        return fail(FDW_EINVAL, "receiver depth %d is not an interior column [%d,%d)", gz, c->prm.nzb, c->prm.nzb + c->nz);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_work_buffers(c, 2, false))) return rc;
+    const size_t nx = c->nx, nrec = nx * (size_t)nt;
+    if ((rc = ensure_cap(&c->d_rec, &c->rec_cap, nrec))) return rc;
+    if ((rc = upload_rows(c, c->d_v2, vel2, c->stream)) || (rc = upload_source(c, srce, nt))) return rc;
+    HIP_TRY(hipMemsetAsync(c->fld[0], 0, field_elems(c) * sizeof(float), c->stream));   // M:144-145
+    HIP_TRY(hipMemsetAsync(c->fld[1], 0, field_elems(c) * sizeof(float), c->stream));
+    float *d_p = c->fld[0], *d_pp = c->fld[1];   // M's P and PP
+    for (int it = 0; it < nt; it++) {
+        // lazy damping: memory holds raw fields; as "p" a field owes one taper_apply, as "pp" two (it was damped once as the new
+        // field and once more as P, M:151-152).  At it = 0 both are zero, so the count does not matter.
+        rc = step_impl(c, FDW_MODE_MOD, d_p, d_pp, c->d_v2, 0, c->nxl, 1, c->d_srce + it, sx, sz, nullptr, nullptr, c->stream,
+                       c->d_rec + (size_t)it * nx, gz);
+        if (rc) return rc;
+        std::swap(d_p, d_pp);                     // M:161-163
+    }
+    std::vector<float> t(nrec);
+    HIP_TRY(hipMemcpyAsync(t.data(), c->d_rec, nrec * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t ix = 0; ix < nx; ix++)            // device [it][ix] -> data[ix][it] (M:156)
+        for (size_t it = 0; it < (size_t)nt; it++) data[ix * nt + it] = t[it * nx + ix];
     return FDW_OK;
 }
 

@@ -185,3 +185,43 @@ void fdw_extendvel_linear(int nx, int nz, int nxb, int nzb, float *vel)
     }
 #undef AT
 }
+
+/* ---- forward-modelling producer of the CPU-serial sibling (DD = dpct_gpu_rtm_domain_division/src) --------------------
+ * DD builds its .c files with g++ (every Makefile there sets CC = g++ -fpermissive), so exp(float) is the float overload. */
+
+/* DD boundary/taper.c:26-44: taper[i] = exp(-pow(F*(nb-i), 2)), the product in float, pow and exp in double */
+void fdw_mod_taper_tables(int nxb, int nzb, float fac, float *taper_x, float *taper_z)
+{
+    for (int i = 0; taper_x && i < nxb; i++) taper_x[i] = exp(-pow((double)(fac * (nxb - i)), 2));
+    for (int i = 0; taper_z && i < nzb; i++) taper_z[i] = exp(-pow((double)(fac * (nzb - i)), 2));
+}
+
+/* DD boundary/taper.c:7-23 */
+void fdw_mod_extendvel(int nx, int nz, int nxb, int nzb, float *vel)
+{
+    const size_t nze = (size_t)nz + 2 * (size_t)nzb;
+    for (int ix = nxb; ix < nxb + nx; ix++) {
+        float *row = vel + (size_t)ix * nze;
+        for (int iz = 0; iz < nzb; iz++) row[iz] = row[nzb];
+        for (size_t iz = (size_t)nzb + nz; iz < nze; iz++) row[iz] = row[nz + nzb - 1];
+    }
+    for (size_t iz = 0; iz < nze; iz++) {
+        for (int ix = 0; ix < nxb; ix++) vel[(size_t)ix * nze + iz] = vel[(size_t)nxb * nze + iz];
+        for (int ix = nxb + nx; ix < nx + 2 * nxb; ix++) vel[(size_t)ix * nze + iz] = vel[(size_t)(nx + nxb - 1) * nze + iz];
+    }
+}
+
+/* DD source/ptsrc.c:60-99 */
+void fdw_mod_ricker_wavelet(int nt, float dt, float fpeak, float *s)
+{
+    for (int it = 0; it < nt; it++) {
+        if (it * dt > 2.0 / fpeak) {
+            s[it] = 0.0f;
+        } else {
+            const float t = it * dt - 1.0 / fpeak;
+            const float x = FDW_PI * fpeak * t;
+            const float xx = x * x;
+            s[it] = expf(-xx) * (1.0 - 2.0 * xx);
+        }
+    }
+}

@@ -8,7 +8,8 @@ enum {
     FDW_MODE_FWD = 0,    // taper + Laplacian + leap-frog + point source   (fd_forward body, R:264-267)
     FDW_MODE_PLAIN = 1,  // Laplacian + leap-frog only                     (fd_back source field, R:317-318)
     FDW_MODE_RECV = 2,   // taper + Laplacian + leap-frog + receivers + imaging (R:325-329)
-    FDW_MODE_LAP = 3     // Laplacian only, written to `pp`                (stencil_code, S:325)
+    FDW_MODE_LAP = 3,    // Laplacian only, written to `pp`                (stencil_code, S:325)
+    FDW_MODE_MOD = 4     // forward-modelling step of the CPU-serial sibling (mod_main: fd_step + ptsrc + taper_apply + trace sample)
 };
 
 constexpr int kMaxFastHalfOrder = 4;   // register-window kernel is instantiated for order 2,4,6,8
@@ -38,6 +39,11 @@ struct StepArgs {
     int xchunk, wz, nzblk, nblk, nper;  // launch geometry (fast kernel)
     float dt2;
     float cx[2 * kMaxFastHalfOrder + 1], cz[2 * kMaxFastHalfOrder + 1];
+    // FDW_MODE_MOD only: cz holds the UNSCALED weights, the spacings come separately (fd.c:24-36 scales per term)
+    float dx2inv, dz2inv;
+    float gw[4][4];        // expf(-(i*i + j*j)): the 7x7 Gaussian point source of ptsrc.c:49-55
+    float* rec;            // this step's trace samples [rec_n]: rec[r - rec_x0] = p(r, rec_z)   (mod_main.cpp:155-157)
+    int rec_z, rec_x0, rec_n;
 };
 
 // Two-steps-per-pass kernel (temporal blocking, order 8, forward mode): see fdw_step2_kernel.

@@ -129,6 +129,19 @@ __device__ __forceinline__ float laplacian_pt(const float* W, int e, const float
     }
     return acmz + acmx;
 }
+// The CPU-serial sibling's Laplacian (dpct_gpu_rtm_domain_division/src/timestep/fd.c:28-36): ONE accumulator, per tap the z term
+// then the x term, each weight scaled by its inverse spacing squared inside the term.  c = unscaled weights.
+template <int H>
+__device__ __forceinline__ float laplacian_dd_pt(const float* W, int e, const float (&col)[2 * H + 1], const float* c, float dx2inv, float dz2inv)
+{
+    float acm = 0.0f;
+#pragma unroll
+    for (int io = 0; io <= 2 * H; ++io) {
+        acm = acm + (W[4 + e - H + io] * c[io]) * dz2inv;
+        acm = acm + (col[io] * c[io]) * dx2inv;
+    }
+    return acm;
+}
 // the update once prod = (v2*dt2)*lap is formed (fp32, as the reference's float expression does; R:89)
 __device__ __forceinline__ float leapfrog_prod(float p, float pp, float prod)
 {
@@ -239,9 +252,10 @@ __device__ __forceinline__ float sload(const float* p, int i)
 // fused step kernel
 //   H       half order (1..4)
 //   TAPER   apply the lazy top-strip damping to p / pp
-//   INJ     0 none, 1 point source (kernel_src), 2 receiver row (kernel_sism)
+//   INJ     0 none, 1 point source (kernel_src), 2 receiver row (kernel_sism), 3 7x7 Gaussian point source (ptsrc.c of the CPU-serial sibling)
 //   IMG     img += psrc * pp_new epilogue (kernel_img)
 //   LAPONLY store the Laplacian itself into a.pp (stencil_code path, S:110-135); no update
+//   DD      arithmetic of the CPU-serial sibling's fd_step (single accumulator, per-term scaling) + one trace sample per row
 //   PF      software prefetch distance in rows
 // block = 256 threads = 4 independent waves (no LDS, no barrier).
 //
@@ -253,7 +267,7 @@ __device__ __forceinline__ float sload(const float* p, int i)
 // >= nze-H.  Edge handling (masks, damping, injection) is wave-uniform branches around VALU / scalar
 // loads only.
 // ------------------------------------------------------------------------------------------------
-template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF>
+template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false>
 __device__ __forceinline__ void march(const StepArgs& a, const int lane, const int zs, const int xa, const int xe)
 {
     using G = RingGeom<H, PF>;
@@ -281,7 +295,9 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
     bool inj_here = false;
     if (INJ == 1) inj_here = (a.inj_x >= xa) && (a.inj_x < xe) && (a.inj_z >= zs) && (a.inj_z < zs + 256);
     if (INJ == 2) inj_here = (a.inj_z >= zs) && (a.inj_z < zs + 256) && (a.inj_x < xe) && (a.inj_x + a.inj_n > xa);
-    const float inj_src = (INJ == 1 && inj_here) ? sload(a.inj, 0) : 0.0f;
+    if (INJ == 3) inj_here = (a.inj_z + 3 >= zs) && (a.inj_z - 3 < zs + 256) && (a.inj_x + 3 >= xa) && (a.inj_x - 3 < xe);   // 7x7 blob
+    const float inj_src = ((INJ == 1 || INJ == 3) && inj_here) ? sload(a.inj, 0) : 0.0f;
+    const bool rec_here = DD && (a.rec != nullptr) && (a.rec_z >= zs) && (a.rec_z < zs + 256);
     const CoefPairs<H> cpk = coef_pairs<H>(a.cx, a.cz);
 
     // per-lane column masks and damping factors
@@ -402,7 +418,26 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
             }
             const bool rowok = (r >= a.lap_x0) && (r < a.lap_x1);
             f4 res, imr;
-            {
+            if constexpr (DD) {
+                if (rec_here && r >= a.rec_x0 && r < a.rec_x0 + a.rec_n) {      // the trace sample of this step: the current field at depth rec_z
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (z0 + e == a.rec_z) a.rec[r - a.rec_x0] = c.v[e];      // interior point: its damping factors are 1.0f
+                }
+                float W[12];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { W[e] = lft.v[e]; W[4 + e] = c.v[e]; W[8 + e] = rgt.v[e]; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float col[2 * H + 1];
+#pragma unroll
+                    for (int io = 0; io <= 2 * H; ++io) col[io] = ring[(U + io) % R].v[e];
+                    float lap = laplacian_dd_pt<H>(W, e, col, a.cz, a.dx2inv, a.dz2inv);
+                    if (zedge || xedge) lap = (rowok && mlap[e]) ? lap : 0.0f;
+                    const float upd = leapfrog_prod(c.v[e], ppt.v[e], (qv2[Q].v[e] * a.dt2) * lap);
+                    res.v[e] = zedge ? (mupd[e] ? upd : ppt.v[e]) : upd;
+                }
+            } else {
                 // packed pairs: same products and sums in the same order as laplacian_pt (see laplacian_pair)
                 const ZPairs zp = zpairs(lft, c, rgt);
                 static_for<2>([&](auto PP) {
@@ -430,6 +465,18 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
                         const float injv = (INJ == 1) ? inj_src : sload(a.inj, r - a.inj_x);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) res.v[e] = ihit[e] ? res.v[e] + injv : res.v[e];
+                    }
+                }
+            }
+            if constexpr (INJ == 3) {
+                if (inj_here && r >= a.inj_x - 3 && r <= a.inj_x + 3) {   // ptsrc.c:49-55: s += ts * exp(-xn*xn - zn*zn), all float
+                    const int dxa = r > a.inj_x ? r - a.inj_x : a.inj_x - r;
+                    const float g0 = a.gw[dxa][0], g1 = a.gw[dxa][1], g2 = a.gw[dxa][2], g3 = a.gw[dxa][3];   // wave-uniform kernarg reads
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int dz = z0 + e - a.inj_z, dza = dz < 0 ? -dz : dz;
+                        const float g = dza == 0 ? g0 : (dza == 1 ? g1 : (dza == 2 ? g2 : g3));
+                        if (dza <= 3) res.v[e] = res.v[e] + inj_src * g;
                     }
                 }
             }
@@ -478,7 +525,7 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
         static_for<R>([&](auto UU) { row_step(rb, UU, std::true_type{}); });
 }
 
-template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF>
+template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false>
 __global__ __launch_bounds__(256) void fdw_step_kernel(const StepArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -500,7 +547,7 @@ __global__ __launch_bounds__(256) void fdw_step_kernel(const StepArgs a)
     const int xa = a.r0 + chunk * a.xchunk;
     const int xe = min(xa + a.xchunk, a.r1);
     if (xa >= xe) return;
-    march<H, TAPER, INJ, IMG, LAPONLY, PF>(a, lane, zs, xa, xe);
+    march<H, TAPER, INJ, IMG, LAPONLY, PF, DD>(a, lane, zs, xa, xe);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1121,6 +1168,7 @@ static hipError_t launch_fast_hp(const StepArgs& a, int mode, hipStream_t s)
     case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_step_kernel<H, false, 0, false, false, PF>), grid, block, 0, s, a); break;
     case FDW_MODE_RECV:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, PF>), grid, block, 0, s, a); break;
     case FDW_MODE_LAP:   hipLaunchKernelGGL((fdw_step_kernel<H, false, 0, false, true, PF>), grid, block, 0, s, a); break;
+    case FDW_MODE_MOD:   hipLaunchKernelGGL((fdw_step_kernel<H, true, 3, false, false, PF, true>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

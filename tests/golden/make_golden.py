@@ -12,6 +12,9 @@ oracle/Makefile from cuda_reference_RTM/lib/src/functions.c).  No reference sour
   new_mod_vel_koslov.f32      cuda_reference_RTM/models/new_mod/vel-koslov.1 (315x195)
   host_tables.npz             calc_coefs / ricker_wavelet / extendvel_linear outputs of oracle/_ref
   decks/*.dat                 the reference's input.dat decks (parser fixtures)
+  dd_3lay_mod_vp_151x151.f32  dpct_gpu_rtm_domain_division/build/3lay_mod/3layer_151x151.bin (velocity model of the CPU-serial sibling)
+  dd_3lay_mod_dobs.f32        dpct_gpu_rtm_domain_division/build/3lay_mod/dobs.bin: the gather its mod_main produced from that
+                              model and decks/dd_3lay_mod.dat (151 traces x 1001 samples) -- known answer of the modelling producer
 """
 import ctypes as C
 import os
@@ -38,8 +41,11 @@ def main():
                       ("new_mod.dat", "cuda_reference_RTM/models/new_mod/input.dat"),
                       ("marmousi.dat", "cuda_reference_RTM/models/marmousi/input.dat"),
                       ("1lay_mod.dat", "cuda_reference_RTM/models/1lay_mod/input.dat"),
-                      ("3lay_mod.dat", "cuda_reference_RTM/models/3lay_mod/input.dat")]:
+                      ("3lay_mod.dat", "cuda_reference_RTM/models/3lay_mod/input.dat"),
+                      ("dd_3lay_mod.dat", "dpct_gpu_rtm_domain_division/build/3lay_mod/input.dat")]:
         cp(src, os.path.join("decks", name))
+    cp("dpct_gpu_rtm_domain_division/build/3lay_mod/3layer_151x151.bin", "dd_3lay_mod_vp_151x151.f32")
+    cp("dpct_gpu_rtm_domain_division/build/3lay_mod/dobs.bin", "dd_3lay_mod_dobs.f32")
 
     L = O.ref_lib()
     assert L is not None, "build oracle/_ref first (make -C oracle)"

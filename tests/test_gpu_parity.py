@@ -531,3 +531,65 @@ def test_dev_step4_row_ranges_vs_oracle():
     with pytest.raises(F.FdwError):
         ctx.dev_step4(newest.data_ptr(), older.data_ptr(), v2.data_ptr(), out1.data_ptr(), out2.data_ptr(), r0=50, r1=90, r0b=80, r1b=120)
     assert ctx.steps_per_pass() == 1 and mk(make_deck(1200, 8192, 16, 16, 4, seed=1, compat=False)).steps_per_pass() == 4
+
+
+# ---- forward-modelling producer (dialect MOD) -----------------------------------------------------------
+def test_model_shot_reproduces_the_reference_gather_bit_exact():
+    """fdw_model_shot on the CPU-serial sibling's own deck (build/3lay_mod): the gather its mod_main wrote, dobs.bin, bit for bit."""
+    from test_oracle_golden import dd_3lay_mod
+    d = dd_3lay_mod()
+    nxe, nze = d["nx"] + 2 * d["nxb"], d["nz"] + 2 * d["nzb"]
+    v2 = F.mod_extendvel(d["v2"], d["nx"], d["nz"], d["nxb"], d["nzb"])
+    assert_bit_equal(v2, O.mod_extendvel(d["v2"].copy(), d["nx"], d["nz"], d["nxb"], d["nzb"]), "extendvel")
+    srce = F.mod_ricker_wavelet(d["nt"], d["dt"], d["fpeak"])
+    assert_bit_equal(srce, O.mod_ricker_wavelet(d["nt"], d["dt"], d["fpeak"]), "ricker with cut-off")
+    ctx = F.FDWave(d["order"], nxe, nze, d["nxb"], d["nzb"], d["nt"], d["fac"], d["dx"], d["dz"], d["dt"], dialect=1)
+    data = ctx.model_shot(v2, d["sx"], d["sz"], d["gz"], srce)
+    assert_bit_equal(data, d["dobs"], "HIP model_shot vs build/3lay_mod/dobs.bin")
+    for xchunk in (1, 7):
+        ctx.set_tuning(xchunk=xchunk)
+        assert_bit_equal(ctx.model_shot(v2, d["sx"], d["sz"], d["gz"], srce), d["dobs"], f"xchunk={xchunk}")
+
+
+MOD_CASES = [
+    # nx, nz, nxb, nzb, nt, order, dx, dz, fac, (sx, sz, gz) interior offsets
+    (61, 47, 17, 13, 40, 8, 10.0, 10.0, 0.02, (5, 1, 2)),
+    (61, 47, 17, 13, 40, 8, 10.0, 12.5, 0.02, (0, 0, 0)),          # source on the corner of the interior
+    (300, 90, 8, 9, 24, 8, 8.0, 10.0, 0.05, (299, 89, 86)),       # several strips along z; source at the far interior corner
+    (40, 600, 5, 30, 20, 8, 10.0, 10.0, 0.03, (20, 250, 255)),    # source blob across a 256-column strip border (z = 30 + 250 .. )
+    (50, 44, 6, 7, 30, 6, 10.0, 10.0, 0.02, (10, 3, 1)),
+    (50, 44, 6, 7, 30, 4, 10.0, 10.0, 0.02, (10, 3, 1)),
+    (50, 44, 6, 7, 30, 2, 10.0, 10.0, 0.02, (10, 3, 1)),
+    (33, 35, 0, 0, 16, 8, 10.0, 10.0, 0.02, (1, 2, 4)),           # no border at all: blob clipped by the array edge
+]
+
+
+@pytest.mark.parametrize("case", MOD_CASES, ids=lambda c: "x".join(map(str, c[:6])))
+def test_model_shot_vs_oracle_bit_exact(case):
+    nx, nz, nxb, nzb, nt, order, dx, dz, fac, (sx0, sz0, gz0) = case
+    nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+    rng = np.random.default_rng(nx * 31 + nz)
+    vp = (1500 + 2500 * rng.random((nx, nz))).astype(np.float32)
+    v2 = np.zeros((nxe, nze), np.float32)
+    v2[nxb:nxb + nx, nzb:nzb + nz] = vp * vp
+    v2 = F.mod_extendvel(v2, nx, nz, nxb, nzb)
+    srce = (F.mod_ricker_wavelet(nt, 0.001, 40.0) + 0.1 * rng.standard_normal(nt)).astype(np.float32)   # non-zero to the last step
+    ctx = F.FDWave(order, nxe, nze, nxb, nzb, nt, fac, dx, dz, 0.001, dialect=1)
+    got = ctx.model_shot(v2, sx0 + nxb, sz0 + nzb, gz0 + nzb, srce)
+    want = O.mod_shot(order, nx, nz, nxb, nzb, dx, dz, 0.001, fac, v2, sx0 + nxb, sz0 + nzb, gz0 + nzb, srce)
+    assert np.abs(want).max() > 0
+    assert_bit_equal(got, want, "gather")
+
+
+def test_model_dialect_guards():
+    ctx = F.FDWave(8, 80, 70, 10, 10, 10, 0.02, 10.0, 10.0, 0.001, dialect=1)
+    v2 = np.full((80, 70), 4e6, np.float32)
+    with pytest.raises(F.FdwError):
+        ctx.forward(v2, 20, 20, np.zeros(10, np.float32))                    # RTM entry points refuse a modelling context
+    with pytest.raises(F.FdwError):
+        ctx.model_shot(v2, 20, 20, 5, np.zeros(10, np.float32))              # receiver depth inside the border
+    with pytest.raises(F.FdwError):
+        mk(make_deck(80, 70, 10, 10, 10, seed=1)).model_shot(v2, 20, 20, 12, np.zeros(10, np.float32))   # RTM context
+    with pytest.raises(F.FdwError):
+        F.FDWave(10, 80, 70, 10, 10, 10, 0.02, 10.0, 10.0, 0.001, dialect=1)  # no generic-order modelling kernel
+    assert ctx.steps_per_pass() == 1

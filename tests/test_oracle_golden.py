@@ -97,3 +97,84 @@ def test_back_is_linear_in_the_data():
     i2 = orc.back(d["v2"], P, PP, 2 * da, d["gz"])
     assert ia.any()
     assert rel_max(i2, 2 * ia) < 1e-5
+
+
+# ---- forward-modelling producer of the CPU-serial sibling (oracle/fdw_oracle_mod.c) -------------------
+def dd_3lay_mod():
+    """dpct_gpu_rtm_domain_division/build/3lay_mod: deck values (decks/dd_3lay_mod.dat), model, and the gather its mod_main wrote."""
+    nx = nz = 151
+    nxb = nzb = 40
+    nt = 1001
+    vp = golden_field("dd_3lay_mod_vp_151x151.f32", (nx, nz))
+    v2 = np.zeros((nx + 2 * nxb, nz + 2 * nzb), np.float32)
+    v2[nxb:nxb + nx, nzb:nzb + nz] = vp * vp                     # mod_main.cpp:121-125
+    return dict(order=8, nx=nx, nz=nz, nxb=nxb, nzb=nzb, nt=nt, dx=10.0, dz=10.0, dt=0.001, fac=0.010, fpeak=30.0, sx=0 + nxb, sz=0 + nzb,
+                gz=0 + nzb, v2=v2, dobs=golden_field("dd_3lay_mod_dobs.f32", (nx, nt)))
+
+
+def test_modelling_producer_known_answer_bit_exact():
+    d = dd_3lay_mod()
+    v2 = O.mod_extendvel(d["v2"], d["nx"], d["nz"], d["nxb"], d["nzb"])
+    srce = O.mod_ricker_wavelet(d["nt"], d["dt"], d["fpeak"])
+    assert srce[:66].any() and not srce[67:].any()             # cut off after 2/fpeak (ptsrc.c:92-94)
+    data = O.mod_shot(d["order"], d["nx"], d["nz"], d["nxb"], d["nzb"], d["dx"], d["dz"], d["dt"], d["fac"], v2, d["sx"], d["sz"], d["gz"], srce)
+    assert_bit_equal(data, d["dobs"], "oracle mod_main loop vs build/3lay_mod/dobs.bin")
+    assert np.abs(d["dobs"]).max() > 1.0
+
+
+def test_modelling_passes_match_the_reference_functions():
+    """Each pass of the restatement against the sibling's own fd.c / taper.c / ptsrc.c compiled unmodified (oracle/_ref/libref_dd.so,
+    C++ symbols because its Makefiles build them with g++)."""
+    import ctypes as C
+    R = O.ref_dd_lib()
+    if R is None:
+        pytest.skip("oracle/_ref/libref_dd.so not built (reference tree absent)")
+    rng = np.random.default_rng(3)
+    nx, nz, nxb, nzb, order = 37, 29, 9, 7, 8
+    nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+    fp = C.POINTER(C.c_float)
+
+    def rows(a):      # float** view of a C-contiguous [n][m] array
+        return (fp * a.shape[0])(*[C.cast(a[i].ctypes.data, fp) for i in range(a.shape[0])])
+
+    # taper tables + taper_apply
+    R._Z10taper_initiif(nxb, nzb, C.c_float(0.05))
+    a = rng.standard_normal((nxe, nze)).astype(np.float32)
+    b = a.copy()
+    R._Z11taper_applyPPfiiii(rows(a), nx, nz, nxb, nzb)
+    tx, tz = O.mod_taper_tables(nxb, nzb, 0.05)
+    O.lib().orc_mod_taper_apply(b, nx, nz, nxb, nzb, np.ascontiguousarray(tx), np.ascontiguousarray(tz))
+    assert_bit_equal(b, a, "taper_apply")
+    # extendvel
+    a = rng.random((nxe, nze)).astype(np.float32)
+    b = a.copy()
+    R._Z9extendveliiiiPf(nx, nz, nxb, nzb, a.ctypes.data_as(fp))
+    assert_bit_equal(O.mod_extendvel(b, nx, nz, nxb, nzb), a, "extendvel")
+    # ricker with cut-off
+    for nt, dt, fpk in ((300, 0.001, 30.0), (500, 0.0007, 17.5)):
+        s = np.zeros(nt, np.float32)
+        R._Z14ricker_waveletiffPf(nt, C.c_float(dt), C.c_float(fpk), s.ctypes.data_as(fp))
+        assert_bit_equal(O.mod_ricker_wavelet(nt, dt, fpk), s, f"ricker_wavelet({nt},{dt},{fpk})")
+    # ptsrc at the corner, an edge and the middle
+    for (xs, zs) in ((0, 0), (2, 20), (nxe - 1, nze - 2), (20, 15)):
+        a = rng.standard_normal((nxe, nze)).astype(np.float32)
+        b = a.copy()
+        R._Z5ptsrciiiifPPf(xs, zs, nxe, nze, C.c_float(1.7), rows(a))
+        O.lib().orc_mod_ptsrc(xs, zs, nxe, nze, 1.7, b)
+        assert_bit_equal(b, a, f"ptsrc at ({xs},{zs})")
+    # fd_step for the table orders
+    for order in (2, 4, 6, 8):
+        R._Z7fd_initiiifff(order, nxe, nze, C.c_float(10.0), C.c_float(12.5), C.c_float(0.001))
+        p = rng.standard_normal((nxe, nze)).astype(np.float32)
+        pp = rng.standard_normal((nxe, nze)).astype(np.float32)
+        v2 = (1500 + 2000 * rng.random((nxe, nze)).astype(np.float32)) ** 2
+        pp_ref = pp.copy()
+        R._Z7fd_stepiPPfS0_S0_ii(order, rows(p), rows(pp_ref), rows(v2), nze, nxe)
+        coefs = O.calc_coefs(order, cxx=True)
+        lap = np.zeros((nxe, nze), np.float32)
+        dx2inv = np.float32((1. / 10.0) * (1. / 10.0))
+        dz2inv = np.float32((1. / 12.5) * (1. / 12.5))
+        O.lib().orc_mod_fd_step(order, np.ascontiguousarray(coefs), dx2inv, dz2inv, np.float32(0.001) * np.float32(0.001), p, pp, v2, lap, nze, nxe)
+        assert_bit_equal(pp, pp_ref, f"fd_step order {order}")
+        R._Z10fd_destroyv()
+    R._Z13taper_destroyv()
