@@ -64,6 +64,79 @@ def cpu_baseline(n, seconds_target=12.0):
                       f"single thread, {dt:.1f} s"}
 
 
+def run_model_workload(args):
+    """`--workload model`: the forward-modelling producer (dialect MOD) -- one launch per time step of
+    fd_step + ptsrc + both taper_apply + trace recording, device resident; same metric, roofline and CPU baseline fields."""
+    import ctypes as C
+    n, K, W = args.size, args.steps, args.warmup
+    nt = K + W
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ctx = F.FDWave(ORDER, n, n, NB, NB, nt, 0.01, DX, DX, DT, dialect=1)
+    pitch = ctx.pitch
+    v2 = torch.zeros((n, pitch), device=dev)
+    v2[:, :n] = synthetic_velocity_rows(n, 0, n, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED0003)
+    p = torch.zeros((n, pitch), device=dev)
+    pp = torch.zeros((n, pitch), device=dev)
+    p[:, :n] = 1e-3 * torch.randn((n, n), device=dev, generator=g)
+    pp[:, :n] = 1e-3 * torch.randn((n, n), device=dev, generator=g)
+    srce = torch.from_numpy(F.mod_ricker_wavelet(nt, DT, FPEAK)).to(dev)
+    rec = torch.zeros((nt, n - 2 * NB), device=dev)
+    stream = torch.cuda.Stream()
+    bufs = [p, pp]
+
+    def run(it0, nsteps):
+        ctx.dev_model_steps(bufs[0].data_ptr(), bufs[1].data_ptr(), v2.data_ptr(), srce.data_ptr(), n // 2, n // 2, NB, rec.data_ptr(), it0, nsteps,
+                            stream=stream.cuda_stream)
+        if nsteps % 2:
+            bufs.reverse()
+
+    run(0, W)
+    stream.synchronize()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    run(W, K)
+    e1.record(stream)
+    while not e1.query():
+        pass
+    stream.synchronize()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    launch_ms = e0.elapsed_time(e1) / K
+    newest = bufs[0]
+    finite = bool(torch.isfinite(newest).all().item()) and float(newest.abs().max().item()) > 0.0 and float(rec.abs().max().item()) > 0.0
+    algo = ALGO_BYTES_PER_POINT * n * n
+    achieved = algo / (launch_ms * 1e-3) / 1e9
+    out = {"metric": "Gpoints/s (stencil updates) + achieved HBM GB/s vs peak", "value": round(n * n * K / wall / 1e9, 3), "unit": "Gpoints/s",
+           "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": round(wall * 1e3 / K, 6), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded noise wavefield)",
+           "config": {"workload": f"forward-modelling producer (mod_main of the CPU-serial sibling): fd_step + 7x7 Gaussian source + four-sided taper + "
+                                  f"trace recording fused in one launch per step, {n}x{n} fp32 extended grid, nxb=nzb={NB}, {K} steps",
+                      "grid": [n, n], "order": ORDER, "parallelism": "single"},
+           "result_finite_nonzero": finite,
+           "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": None, "kernel": "fdw::fdw_step_kernel<4,true,3,false,false,2,true>", "launch_us": round(launch_ms * 1e3, 2),
+                        "steps_per_launch": 1, "algorithmic_bytes_per_launch": algo}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        m = min(n, 2048)                       # bounded sample: the oracle's mod loop (with its own allocation and tables) on an m x m grid
+        nti = 400                              # ~10 s of one core
+        hv2 = np.full((m, m), 2500.0 ** 2, np.float32)
+        hs = F.mod_ricker_wavelet(nti, DT, FPEAK)
+        t0 = time.perf_counter()
+        O.mod_shot(ORDER, m - 2 * NB, m - 2 * NB, NB, NB, DX, DX, DT, 0.01, hv2, m // 2, m // 2, NB, hs)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(m * m * nti / dt / 1e9, 4), "unit": "Gpoints/s", "cores": 1, "kind": "port",
+                               "sample": f"{m}x{m} fp32 grid, {nti} steps of oracle/fdw_oracle_mod.c orc_mod_shot (gcc -O2 -ffp-contract=off), single thread, {dt:.1f} s"}
+    print(json.dumps(out), flush=True)
+    if not finite:
+        sys.exit("bench: result is not finite / all zero")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +146,8 @@ def main():
     ap.add_argument("--ksteps", type=int, default=0, help="time steps per halo exchange (N > 1); 0 = auto")
     ap.add_argument("--pipe", choices=("auto", "on", "off"), default="auto",
                     help="N > 1: four-steps-per-pass wave-pipeline kernel inside the slabs (auto = where the library would pick it)")
+    ap.add_argument("--workload", choices=("forward", "model"), default="forward",
+                    help="forward: the headline fused forward step of rtm_code (default); model: the forward-modelling producer (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU rehearsals)")
@@ -80,6 +155,12 @@ def main():
     ap.add_argument("--init", choices=["noise", "rest"], default="noise",
                     help="initial wavefield: seeded noise (default; every cache line carries real data) or at rest (zeros + source)")
     args = ap.parse_args()
+    if args.workload == "model":
+        if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            sys.exit("bench --workload model runs on one GPU")
+        if not torch.cuda.is_available():
+            sys.exit("bench: no GPU visible (the product has no CPU path)")
+        return run_model_workload(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -169,6 +169,9 @@ int fdw_dev_laplacian(fdw_ctx *ctx, const float *d_p, float *d_lap, void *stream
  * fdw_mod_ricker_wavelet  ptsrc.c:88-99: Ricker delayed by 1/fpeak, zero after 2/fpeak
  * fdw_mod_taper_tables    taper.c:26-44 */
 int fdw_model_shot(fdw_ctx *ctx, const float *vel2, int sx, int sz, int gz, const float *srce, int nt, float *data);
+/* the same loop on caller-owned device arrays (d_p / d_pp = mod_main's P / PP, swapped every step; d_rec[it][nx] or NULL) */
+int fdw_dev_model_steps(fdw_ctx *ctx, float *d_p, float *d_pp, const float *d_v2, const float *d_srce, int sx, int sz, int gz,
+                        float *d_rec, int it0, int nsteps, void *stream);
 void fdw_mod_extendvel(int nx, int nz, int nxb, int nzb, float *vel);
 void fdw_mod_ricker_wavelet(int nt, float dt, float fpeak, float *srce);
 void fdw_mod_taper_tables(int nxb, int nzb, float fac, float *taper_x, float *taper_z);

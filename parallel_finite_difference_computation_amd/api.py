@@ -182,6 +182,9 @@ class FDWave:
         check(lib().fdw_model_shot(self._h, _f32(vel2, (self.nxe, self.nze)), sx, sz, gz, srce, srce.size, data))
         return data
 
+    def dev_model_steps(self, d_p, d_pp, d_v2, d_srce, sx, sz, gz, d_rec, it0, nsteps, stream=None):
+        check(lib().fdw_dev_model_steps(self._h, d_p, d_pp, d_v2, d_srce, sx, sz, gz, d_rec, it0, nsteps, stream))
+
     # ---- device-array API (raw pointers; see device.py for torch helpers) -----------------------
     def dev_step(self, mode, d_p, d_pp, d_v2, r0=0, r1=None, pp_twice=True, d_inj=None, inj_x=-1, inj_z=0,
                  d_psrc=None, d_img=None, stream=None):

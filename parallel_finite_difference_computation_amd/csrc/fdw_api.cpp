@@ -953,6 +953,24 @@ extern "C" int fdw_set_tuning(fdw_ctx* c, int xchunk, int wz, int use_generic, i
 // ------------------------------------------------------------------------------------------------
 // forward-modelling producer (dialect MOD): mod_main.cpp:140-174
 // ------------------------------------------------------------------------------------------------
+// nsteps iterations of M:147-164 on caller-owned device arrays: d_p / d_pp are M's P / PP (roles swap every step, as there),
+// d_rec [>= (it0+nsteps)][nx] receives the trace samples of iteration it at row it (NULL: not recorded).
+extern "C" int fdw_dev_model_steps(fdw_ctx* c, float* d_p, float* d_pp, const float* d_v2, const float* d_srce, int sx, int sz, int gz,
+                                   float* d_rec, int it0, int nsteps, void* stream)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    if (c->prm.dialect != FDW_DIALECT_MOD) return fail(FDW_ESTATE, "fdw_dev_model_steps needs a context created with dialect = FDW_DIALECT_MOD");
+    hipStream_t s = pick_stream(c, stream);
+    for (int k = 0; k < nsteps; k++) {
+        const int it = it0 + k;
+        int rc = step_impl(c, FDW_MODE_MOD, d_p, d_pp, d_v2, 0, c->nxl, 1, d_srce ? d_srce + it : nullptr, sx, sz, nullptr, nullptr, s,
+                           d_rec ? d_rec + (size_t)it * c->nx : nullptr, gz);
+        if (rc) return rc;
+        std::swap(d_p, d_pp);
+    }
+    return FDW_OK;
+}
+
 extern "C" int fdw_model_shot(fdw_ctx* c, const float* vel2, int sx, int sz, int gz, const float* srce, int nt, float* data)
 {
     if (!c || !vel2 || !data || (!srce && nt > 0)) return fail(FDW_EINVAL, "NULL argument");
@@ -969,15 +987,9 @@ extern "C" int fdw_model_shot(fdw_ctx* c, const float* vel2, int sx, int sz, int
     if ((rc = upload_rows(c, c->d_v2, vel2, c->stream)) || (rc = upload_source(c, srce, nt))) return rc;
     HIP_TRY(hipMemsetAsync(c->fld[0], 0, field_elems(c) * sizeof(float), c->stream));   // M:144-145
     HIP_TRY(hipMemsetAsync(c->fld[1], 0, field_elems(c) * sizeof(float), c->stream));
-    float *d_p = c->fld[0], *d_pp = c->fld[1];   // M's P and PP
-    for (int it = 0; it < nt; it++) {
-        // lazy damping: memory holds raw fields; as "p" a field owes one taper_apply, as "pp" two (it was damped once as the new
-        // field and once more as P, M:151-152).  At it = 0 both are zero, so the count does not matter.
-        rc = step_impl(c, FDW_MODE_MOD, d_p, d_pp, c->d_v2, 0, c->nxl, 1, c->d_srce + it, sx, sz, nullptr, nullptr, c->stream,
-                       c->d_rec + (size_t)it * nx, gz);
-        if (rc) return rc;
-        std::swap(d_p, d_pp);                     // M:161-163
-    }
+    // lazy damping: memory holds raw fields; as "p" a field owes one taper_apply, as "pp" two (it was damped once as the new
+    // field and once more as P, M:151-152).  At it = 0 both are zero, so the count does not matter.
+    if ((rc = fdw_dev_model_steps(c, c->fld[0], c->fld[1], c->d_v2, c->d_srce, sx, sz, gz, c->d_rec, 0, nt, c->stream))) return rc;
     std::vector<float> t(nrec);
     HIP_TRY(hipMemcpyAsync(t.data(), c->d_rec, nrec * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
