@@ -60,7 +60,9 @@ typedef struct fdw_params {
                        fd_step's single accumulator (timestep/fd.c:24-46), four-sided taper_apply with taper = exp(-(F*(nb-i))^2)
                        (boundary/taper.c:26-66), whole-grid update; order <= 8; only fdw_model_shot and the host helpers use it */
 } fdw_params;
-enum { FDW_DIALECT_RTM = 0, FDW_DIALECT_MOD = 1 };
+enum { FDW_DIALECT_RTM = 0, FDW_DIALECT_MOD = 1, FDW_DIALECT_RTM_STORED = 2 };
+/* 2 (FDW_DIALECT_RTM_STORED): the same sibling's stored-wavefield RTM (src/rtm_main.cpp): fd_step arithmetic as dialect 1, one-cell
+ * source, taper_apply2 (top strip only, taper.c:68-83) with the taper table of dialect 1; only fdw_rtm_stored_shot uses it. */
 
 /* A slab of the global grid owned by one device (domain decomposition along x, the slow axis).
  * The reference has no multi-GPU path; slab 0..nxe is the single-GPU case. */
@@ -175,6 +177,16 @@ int fdw_dev_model_steps(fdw_ctx *ctx, float *d_p, float *d_pp, const float *d_v2
 void fdw_mod_extendvel(int nx, int nz, int nxb, int nzb, float *vel);
 void fdw_mod_ricker_wavelet(int nt, float dt, float fpeak, float *srce);
 void fdw_mod_taper_tables(int nxb, int nzb, float fac, float *taper_x, float *taper_z);
+
+/* ---- stored-wavefield RTM of the CPU-serial sibling ----------------------------------------
+ * fdw_rtm_stored_shot  one shot of rtm_main's loop (dpct_gpu_rtm_domain_division/src/rtm_main.cpp:158-240) on a context created with
+ *                 dialect = FDW_DIALECT_RTM_STORED: the source pass keeps the field of every step on the device (nt fields: fails with
+ *                 FDW_ENOMEM when they do not fit), the receiver pass injects sample nt-it of every trace of shot `is` -- read from the
+ *                 WHOLE gather dobs[ns][nx][nt] of n_floats floats exactly as the reference indexes it, i.e. one sample past the trace at
+ *                 it = 0 (a sample past the end of the file counts as 0) and with its nzb row offset (rtm_main.cpp:203) -- and the image
+ *                 accumulates swf[nt-it-1] * rwf[it] in iteration order (same sums as rtm_main.cpp:224-230).  imloc[nx][nz] is overwritten. */
+int fdw_rtm_stored_shot(fdw_ctx *ctx, const float *vel2, int sx, int sz, int gz, const float *srce, int nt, const float *dobs,
+                        size_t n_floats, int is, float *imloc);
 
 /* host <-> pitched device copies (dense [rows][nze] on the host side), synchronous */
 int fdw_upload_field(fdw_ctx *ctx, float *d_dst, const float *h_src);

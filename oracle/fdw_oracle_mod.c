@@ -133,3 +133,68 @@ void orc_mod_shot(int order, int nx, int nz, int nxb, int nzb, int nt, float dx,
     }
     free(P); free(PP); free(lap); free(taperx); free(taperz);
 }
+
+/* ======================================================================================================================
+ * Stored-wavefield RTM of the same sibling: RM = dpct_gpu_rtm_domain_division/src/rtm_main.cpp.
+ * Same fd_step; point source on ONE cell; taper_apply2 (top strip only, x factors only inside it: T:68-83); the source
+ * wavefield of every step is kept and the image is formed from the stored fields.
+ * Pin: orc_rtm_stored_shot reproduces build/3lay_mod/dir.image bit-exactly from that deck, model and dobs.bin.
+ * ====================================================================================================================== */
+
+/* T:68-83 taper_apply2 */
+void orc_mod_taper_apply2(float *pp, int nx, int nz, int nxb, int nzb, const float *taperx, const float *taperz)
+{
+    const int nze = nz + 2 * nzb;
+    for (int itx = 0; itx < nx + 2 * nxb; itx++)
+        for (int itz = 0; itz < nzb; itz++) pp[itx * nze + itz] *= taperz[itz];
+    for (int itx = 0, itxr = nx + 2 * nxb - 1; itx < nxb; itx++, itxr--)
+        for (int itz = 0; itz < nzb; itz++) {
+            pp[itx * nze + itz] *= taperx[itx];
+            pp[itxr * nze + itz] *= taperx[itx];
+        }
+}
+
+/* RM:158-240 for one shot.  dobs_flat is the WHOLE gather file [ns][nx][nt] (n_flat floats) and `is` the shot: the reference reads
+ * sample nt-it of trace ix (RM:203), i.e. one sample past the trace at it = 0 -- the first sample of the next trace, or, for the last
+ * trace of the last shot, one float past the allocation (taken as 0 here).  It also offsets the receiver rows by nzb, not nxb
+ * (RM:203), which is kept.  imloc[nx][nz] is overwritten (RM:189). */
+void orc_rtm_stored_shot(int order, int nx, int nz, int nxb, int nzb, int nt, float dx, float dz, float dt, float fac, const float *v2, int sx,
+                         int sz, int gz, const float *srce, const float *dobs_flat, size_t n_flat, int is, float *imloc)
+{
+    const int nxe = nx + 2 * nxb, nze = nz + 2 * nzb;
+    const size_t ne = (size_t)nxe * nze, ni = (size_t)nx * nz;
+    const float dx2inv = (1. / dx) * (1. / dx), dz2inv = (1. / dz) * (1. / dz), dt2 = dt * dt;
+    float coefs[65];
+    orc_calc_coefs(order, 1, coefs);
+    float *taperx = (float *)malloc(sizeof(float) * (nxb > 0 ? nxb : 1)), *taperz = (float *)malloc(sizeof(float) * (nzb > 0 ? nzb : 1));
+    orc_mod_taper_tables(nxb, nzb, fac, taperx, taperz);
+    float *P = (float *)calloc(ne, sizeof(float)), *PP = (float *)calloc(ne, sizeof(float)), *lap = (float *)calloc(ne, sizeof(float));
+    float *swf = (float *)calloc(ni * (size_t)nt, sizeof(float)), *rwf = (float *)calloc(ni * (size_t)nt, sizeof(float));
+    for (int it = 0; it < nt; it++) {
+        orc_mod_fd_step(order, coefs, dx2inv, dz2inv, dt2, P, PP, v2, lap, nze, nxe);
+        PP[(size_t)sx * nze + sz] += srce[it];
+        orc_mod_taper_apply2(PP, nx, nz, nxb, nzb, taperx, taperz);
+        orc_mod_taper_apply2(P, nx, nz, nxb, nzb, taperx, taperz);
+        for (int ix = 0; ix < nx; ix++)
+            for (int iz = 0; iz < nz; iz++) swf[(size_t)it * ni + (size_t)ix * nz + iz] = P[(size_t)(ix + nxb) * nze + iz + nzb];
+        float *tmp = PP; PP = P; P = tmp;
+    }
+    memset(P, 0, ne * sizeof(float));
+    memset(PP, 0, ne * sizeof(float));
+    memset(imloc, 0, ni * sizeof(float));
+    for (int it = 0; it < nt; it++) {
+        orc_mod_fd_step(order, coefs, dx2inv, dz2inv, dt2, P, PP, v2, lap, nze, nxe);
+        for (int ix = 0; ix < nx; ix++) {
+            const size_t k = ((size_t)is * nx + ix) * nt + (size_t)(nt - it);
+            PP[(size_t)(ix + nzb) * nze + gz] += k < n_flat ? dobs_flat[k] : 0.0f;
+        }
+        orc_mod_taper_apply2(PP, nx, nz, nxb, nzb, taperx, taperz);
+        orc_mod_taper_apply2(P, nx, nz, nxb, nzb, taperx, taperz);
+        for (int ix = 0; ix < nx; ix++)
+            for (int iz = 0; iz < nz; iz++) rwf[(size_t)it * ni + (size_t)ix * nz + iz] = P[(size_t)(ix + nxb) * nze + iz + nzb];
+        float *tmp = PP; PP = P; P = tmp;
+    }
+    for (int it = 0; it < nt; it++)
+        for (size_t k = 0; k < ni; k++) imloc[k] += swf[(size_t)(nt - it - 1) * ni + k] * rwf[(size_t)it * ni + k];
+    free(P); free(PP); free(lap); free(swf); free(rwf); free(taperx); free(taperz);
+}

@@ -48,6 +48,8 @@ def lib():
         L.orc_mod_fd_step.argtypes = [C.c_int, f32p, C.c_float, C.c_float, C.c_float, f32p, f32p, f32p, f32p, C.c_int, C.c_int]
         L.orc_mod_ptsrc.argtypes = [C.c_int] * 4 + [C.c_float, f32p]
         L.orc_mod_shot.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p]
+        L.orc_mod_taper_apply2.argtypes = [f32p] + [C.c_int] * 4 + [f32p, f32p]
+        L.orc_rtm_stored_shot.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_size_t, C.c_int, f32p]
         _LIB = L
     return _LIB
 
@@ -180,6 +182,16 @@ def mod_shot(order, nx, nz, nxb, nzb, dx, dz, dt, fac, vel2, sx, sz, gz, srce):
     data = np.zeros((nx, srce.size), np.float32)
     lib().orc_mod_shot(order, nx, nz, nxb, nzb, srce.size, dx, dz, dt, fac, np.ascontiguousarray(vel2, np.float32), sx, sz, gz, srce, data)
     return data
+
+
+def rtm_stored_shot(order, nx, nz, nxb, nzb, dx, dz, dt, fac, vel2, sx, sz, gz, srce, dobs, shot=0):
+    """rtm_main's loop for one shot (rtm_main.cpp:158-240): imloc[nx][nz]; dobs is the whole gather [ns][nx][nt]."""
+    srce = np.ascontiguousarray(srce, np.float32)
+    dobs = np.ascontiguousarray(dobs, np.float32).ravel()
+    imloc = np.zeros((nx, nz), np.float32)
+    lib().orc_rtm_stored_shot(order, nx, nz, nxb, nzb, srce.size, dx, dz, dt, fac, np.ascontiguousarray(vel2, np.float32), sx, sz, gz, srce,
+                              dobs, dobs.size, shot, imloc)
+    return imloc
 
 
 def ref_dd_lib():

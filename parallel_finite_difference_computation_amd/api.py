@@ -81,7 +81,7 @@ class FDWave:
     def __init__(self, order, nxe, nze, nxb=0, nzb=0, nt=0, fac=1.0, dx=1.0, dz=1.0, dt=0.0, *, compat=True,
                  coef_cxx=False, device=0, slab=None, dialect=0):
         """dialect 0: the CUDA programs (stencil_code / rtm_code); 1: the forward-modelling producer of the CPU-serial sibling
-        (mod_main: model_shot only)."""
+        (mod_main: model_shot only); 2: its stored-wavefield RTM (rtm_main: rtm_stored_shot only)."""
         self.params = Params(order, nxe, nze, nxb, nzb, nt, dx, dz, dt, fac, int(compat), int(coef_cxx), int(dialect))
         self._h = C.c_void_p()
         if slab is None:
@@ -181,6 +181,15 @@ class FDWave:
         data = np.zeros((self.nx, srce.size), np.float32)
         check(lib().fdw_model_shot(self._h, _f32(vel2, (self.nxe, self.nze)), sx, sz, gz, srce, srce.size, data))
         return data
+
+    def rtm_stored_shot(self, vel2, sx, sz, gz, srce, dobs, shot=0):
+        """One shot of the sibling's stored-wavefield RTM (dpct_gpu_rtm_domain_division/src/rtm_main.cpp:158-240); dobs is the WHOLE
+        gather [ns][nx][nt] (the reference reads one sample past each trace, see fdwave.h).  Returns imloc[nx][nz]."""
+        srce = _f32(srce)
+        dobs = np.ascontiguousarray(dobs, np.float32).ravel()
+        imloc = np.zeros((self.nx, self.nz), np.float32)
+        check(lib().fdw_rtm_stored_shot(self._h, _f32(vel2, (self.nxe, self.nze)), sx, sz, gz, srce, srce.size, dobs, dobs.size, shot, imloc))
+        return imloc
 
     def dev_model_steps(self, d_p, d_pp, d_v2, d_srce, sx, sz, gz, d_rec, it0, nsteps, stream=None):
         check(lib().fdw_dev_model_steps(self._h, d_p, d_pp, d_v2, d_srce, sx, sz, gz, d_rec, it0, nsteps, stream))

@@ -137,9 +137,9 @@ static int validate(const fdw_params* p, const fdw_slab* s)
         return fail(FDW_EINVAL, "fac=%g must be in (0,1]", (double)p->fac);
     if (!(p->dx > 0.0f) || !(p->dz > 0.0f)) return fail(FDW_EINVAL, "dx, dz must be positive");
     if (p->nt < 0) return fail(FDW_EINVAL, "nt=%d is negative", p->nt);
-    if (p->dialect != FDW_DIALECT_RTM && p->dialect != FDW_DIALECT_MOD) return fail(FDW_EINVAL, "dialect=%d is unknown", p->dialect);
-    if (p->dialect == FDW_DIALECT_MOD && p->order > 2 * kMaxFastHalfOrder)
-        return fail(FDW_EINVAL, "dialect MOD is built for orders 2..%d", 2 * kMaxFastHalfOrder);
+    if (p->dialect < FDW_DIALECT_RTM || p->dialect > FDW_DIALECT_RTM_STORED) return fail(FDW_EINVAL, "dialect=%d is unknown", p->dialect);
+    if (p->dialect != FDW_DIALECT_RTM && p->order > 2 * kMaxFastHalfOrder)
+        return fail(FDW_EINVAL, "dialects 1 and 2 are built for orders 2..%d", 2 * kMaxFastHalfOrder);
     if (s->nxl <= p->order || s->x_off < 0 || s->x_off + s->nxl > p->nxe)
         return fail(FDW_EINVAL, "slab [%d,%d) does not fit the grid (nxe=%d) or is thinner than the stencil",
                     s->x_off, s->x_off + s->nxl, p->nxe);
@@ -183,11 +183,12 @@ extern "C" int fdw_create_slab(const fdw_params* prm, const fdw_slab* slab, int 
     }
 
     // launch extents, R:185-195 (the int assignment truncates before ceil)
-    const bool mod = prm->dialect == FDW_DIALECT_MOD;
-    if (mod) {                    // fd.c:24-46 and taper.c:46-66 walk the whole array; the z table spans the whole row
+    const bool mod = prm->dialect != FDW_DIALECT_RTM;              // the CPU-serial sibling's arithmetic (fd.c)
+    const bool four_sided = prm->dialect == FDW_DIALECT_MOD;       // taper_apply (mod_main) vs taper_apply2 (rtm_main)
+    if (mod) {                    // fd.c:24-46 and taper.c walk the whole array; taper_apply's z table spans the whole row
         c->xlim = prm->nxe;
         c->zlim = prm->nze;
-        c->ztap = prm->nze;
+        c->ztap = four_sided ? prm->nze : prm->nzb;
     } else if (prm->compat) {
         c->xlim = 8 * (prm->nxe / 8);
         c->zlim = 8 * (prm->nze / 8);
@@ -232,13 +233,14 @@ extern "C" int fdw_create_slab(const fdw_params* prm, const fdw_slab* slab, int 
     c->taper_z.assign(std::max(prm->nzb, 1), 1.0f);
     if (mod) {
         fdw_mod_taper_tables(prm->nxb, prm->nzb, prm->fac, c->taper_x.data(), c->taper_z.data());
-        // taper.c:50-56 as ONE factor per column: top strip, 1.0f, mirrored bottom strip
-        std::vector<float> full(prm->nze, 1.0f);
-        for (int i = 0; i < prm->nzb; i++) {
-            full[i] = c->taper_z[i];
-            full[prm->nze - 1 - i] = c->taper_z[i];
-        }
-        c->taper_z.swap(full);
+        if (four_sided) {         // taper.c:50-56 as ONE factor per column: top strip, 1.0f, mirrored bottom strip
+            std::vector<float> full(prm->nze, 1.0f);
+            for (int i = 0; i < prm->nzb; i++) {
+                full[i] = c->taper_z[i];
+                full[prm->nze - 1 - i] = c->taper_z[i];
+            }
+            c->taper_z.swap(full);
+        }                         // taper_apply2 (taper.c:68-83) has the CUDA path's shape: z factors on the top strip, x factors inside it only
     } else {
         if (prm->nxb > 0) fdw_taper_tables(prm->nxb, 0, prm->fac, c->taper_x.data(), nullptr);
         if (prm->nzb > 0) fdw_taper_tables(0, prm->nzb, prm->fac, nullptr, c->taper_z.data());
@@ -340,9 +342,10 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
     const bool lap = (mode == FDW_MODE_LAP);
     if (!d_p || !d_pp) return fail(FDW_EINVAL, "step: field pointer is NULL");
     if (!lap && !d_v2) return fail(FDW_EINVAL, "step: v2 is NULL");
-    if (mode == FDW_MODE_RECV && (!d_psrc || !d_img || !d_inj)) return fail(FDW_EINVAL, "step: RECV needs d_inj, d_psrc and d_img");
-    if (mode < FDW_MODE_FWD || mode > FDW_MODE_MOD) return fail(FDW_EINVAL, "step: unknown mode %d", mode);
-    if ((mode == FDW_MODE_MOD) != (c->prm.dialect == FDW_DIALECT_MOD))
+    if ((mode == FDW_MODE_RECV || mode == FDW_MODE_DD_RECV) && (!d_psrc || !d_img || !d_inj)) return fail(FDW_EINVAL, "step: RECV needs d_inj, d_psrc and d_img");
+    if (mode < FDW_MODE_FWD || mode > FDW_MODE_DD_RECV) return fail(FDW_EINVAL, "step: unknown mode %d", mode);
+    const int mode_dialect = mode == FDW_MODE_MOD ? FDW_DIALECT_MOD : (mode >= FDW_MODE_DD_FWD ? FDW_DIALECT_RTM_STORED : FDW_DIALECT_RTM);
+    if (mode_dialect != c->prm.dialect)
         return fail(FDW_ESTATE, "step: mode %d does not belong to this context's dialect %d", mode, c->prm.dialect);
     if (r0 < 0 || r1 > c->nxl || r0 > r1) return fail(FDW_EINVAL, "step: rows [%d,%d) outside the slab (%d rows)", r0, r1, c->nxl);
 
@@ -358,7 +361,8 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
     a.ztap = c->ztap; a.tz_x1 = c->tz_x1; a.xt_lo = c->xt_lo; a.xt_hi = c->xt_hi;
     a.pp_twice = pp_twice ? 1 : 0;
     a.inj_x = -1; a.inj_z = inj_z; a.inj_n = 0;
-    if (mode == FDW_MODE_FWD && d_inj && inj_x_global >= 0) {
+    if (mode >= FDW_MODE_DD_FWD) { a.dx2inv = c->dx2inv; a.dz2inv = c->dz2inv; }
+    if ((mode == FDW_MODE_FWD || mode == FDW_MODE_DD_FWD) && d_inj && inj_x_global >= 0) {
         if (inj_z < 0 || inj_z >= c->prm.nze || inj_x_global >= c->prm.nxe)
             return fail(FDW_EINVAL, "step: source (%d,%d) outside the grid", inj_x_global, inj_z);
         a.inj_x = inj_x_global - c->slab.x_off;   // may fall outside this slab: then no row matches
@@ -378,10 +382,13 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
         a.rec = d_rec_row; a.rec_z = rec_z;
         a.rec_x0 = c->prm.nxb - c->slab.x_off; a.rec_n = c->nx;
         if (d_rec_row && (rec_z < 0 || rec_z >= c->prm.nze)) return fail(FDW_EINVAL, "step: receiver depth %d outside the grid", rec_z);
-    } else if (mode == FDW_MODE_RECV) {
+    } else if (mode == FDW_MODE_RECV || mode == FDW_MODE_DD_RECV) {
         if (inj_z < 0 || inj_z >= c->prm.nze) return fail(FDW_EINVAL, "step: receiver depth %d outside the grid", inj_z);
-        // receivers sit on interior columns nxb..nxb+nx-1 (R:126-129); clip to this slab
-        const int g0 = c->prm.nxb, g1 = c->prm.nxb + std::min(c->nx, c->xlim);
+        // receivers sit on interior columns nxb..nxb+nx-1 (R:126-129); clip to this slab.  The sibling's rtm_main offsets them by
+        // nzb instead (PP[ix+nzb][gz], rtm_main.cpp:203) -- the same thing only when both borders are equally wide; kept as is.
+        const int off = mode == FDW_MODE_DD_RECV ? c->prm.nzb : c->prm.nxb;
+        if (off + c->nx > c->prm.nxe) return fail(FDW_EINVAL, "step: receiver rows [%d,%d) leave the grid", off, off + c->nx);
+        const int g0 = off, g1 = off + std::min(c->nx, c->xlim);
         const int l0 = std::max(g0 - c->slab.x_off, 0), l1 = std::min(g1 - c->slab.x_off, c->nxl);
         a.inj_x = l0;
         a.inj_n = std::max(0, l1 - l0);
@@ -398,7 +405,7 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
         fill_geometry(c, a, a.r1 - a.r0);
         e = launch_step_fast(a, c->h, mode, effective_prefetch(c), s);
     } else {
-        if (mode == FDW_MODE_MOD) return fail(FDW_EINVAL, "step: the modelling dialect has no generic-order kernel");
+        if (mode >= FDW_MODE_MOD) return fail(FDW_EINVAL, "step: dialects 1 and 2 have no generic-order kernel");
         e = launch_step_generic(a, c->h, mode, s);
     }
     if (e != hipSuccess) return fail(FDW_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -995,6 +1002,62 @@ extern "C" int fdw_model_shot(fdw_ctx* c, const float* vel2, int sx, int sz, int
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (size_t ix = 0; ix < nx; ix++)            // device [it][ix] -> data[ix][it] (M:156)
         for (size_t it = 0; it < (size_t)nt; it++) data[ix * nt + it] = t[it * nx + ix];
+    return FDW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stored-wavefield RTM (dialect RTM_STORED): rtm_main.cpp:158-240
+// ------------------------------------------------------------------------------------------------
+extern "C" int fdw_rtm_stored_shot(fdw_ctx* c, const float* vel2, int sx, int sz, int gz, const float* srce, int nt, const float* dobs,
+                                   size_t n_floats, int is, float* imloc)
+{
+    if (!c || !vel2 || !imloc || !dobs || (!srce && nt > 0)) return fail(FDW_EINVAL, "NULL argument");
+    if (c->prm.dialect != FDW_DIALECT_RTM_STORED) return fail(FDW_ESTATE, "fdw_rtm_stored_shot needs a context created with dialect = FDW_DIALECT_RTM_STORED");
+    if (!is_full_grid(c)) return fail(FDW_EINVAL, "fdw_rtm_stored_shot needs a full-grid context");
+    if (nt < 0 || is < 0) return fail(FDW_EINVAL, "nt=%d is=%d", nt, is);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_work_buffers(c, 2, true))) return rc;
+    const size_t nx = c->nx, fe = field_elems(c);
+    // the source wavefield of every step (rtm_main.cpp:177-181 keeps the interior; whole pitched fields here so that the imaging
+    // epilogue of the step kernel can read them like any other field)
+    float* d_swf = nullptr;
+    if (nt > 0) {
+        hipError_t e = hipMalloc((void**)&d_swf, fe * (size_t)nt * sizeof(float));
+        if (e != hipSuccess) return fail(FDW_ENOMEM, "the %d stored source fields need %zu bytes: %s", nt, fe * (size_t)nt * sizeof(float), hipGetErrorString(e));
+    }
+    struct Free { float* p; ~Free() { if (p) (void)hipFree(p); } } guard{d_swf};
+    // receiver samples as the reference indexes them: step it reads dobs[is][ix][nt - it]
+    std::vector<float> rows(std::max<size_t>(nx * (size_t)nt, 1));
+    for (int it = 0; it < nt; it++)
+        for (size_t ix = 0; ix < nx; ix++) {
+            const size_t k = ((size_t)is * nx + ix) * (size_t)nt + (size_t)(nt - it);
+            rows[(size_t)it * nx + ix] = k < n_floats ? dobs[k] : 0.0f;
+        }
+    if ((rc = ensure_cap(&c->d_dobs, &c->dobs_cap, rows.size()))) return rc;
+    HIP_TRY(hipMemcpy(c->d_dobs, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+    if ((rc = upload_rows(c, c->d_v2, vel2, c->stream)) || (rc = upload_source(c, srce, nt))) return rc;
+    float *d_p = c->fld[0], *d_pp = c->fld[1];
+    HIP_TRY(hipMemsetAsync(d_p, 0, fe * sizeof(float), c->stream));     // rtm_main.cpp:161-162
+    HIP_TRY(hipMemsetAsync(d_pp, 0, fe * sizeof(float), c->stream));
+    for (int it = 0; it < nt; it++) {
+        rc = step_impl(c, FDW_MODE_DD_FWD, d_p, d_pp, c->d_v2, 0, c->nxl, 1, c->d_srce + it, sx, sz, nullptr, nullptr, c->stream);
+        if (rc) return rc;
+        // swf[it] = P (rtm_main.cpp:177-181): the step leaves its p input untouched, and an interior point is never damped
+        HIP_TRY(hipMemcpyAsync(d_swf + (size_t)it * fe, d_p, fe * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        std::swap(d_p, d_pp);
+    }
+    HIP_TRY(hipMemsetAsync(d_p, 0, fe * sizeof(float), c->stream));     // rtm_main.cpp:187-189
+    HIP_TRY(hipMemsetAsync(d_pp, 0, fe * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_img, 0, fe * sizeof(float), c->stream));
+    for (int it = 0; it < nt; it++) {
+        rc = step_impl(c, FDW_MODE_DD_RECV, d_p, d_pp, c->d_v2, 0, c->nxl, 1, c->d_dobs + (size_t)it * nx, -1, gz,
+                       d_swf + (size_t)(nt - it - 1) * fe, c->d_img, c->stream);
+        if (rc) return rc;
+        std::swap(d_p, d_pp);
+    }
+    if ((rc = image_to_host(c, imloc))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return FDW_OK;
 }
 

@@ -9,7 +9,9 @@ enum {
     FDW_MODE_PLAIN = 1,  // Laplacian + leap-frog only                     (fd_back source field, R:317-318)
     FDW_MODE_RECV = 2,   // taper + Laplacian + leap-frog + receivers + imaging (R:325-329)
     FDW_MODE_LAP = 3,    // Laplacian only, written to `pp`                (stencil_code, S:325)
-    FDW_MODE_MOD = 4     // forward-modelling step of the CPU-serial sibling (mod_main: fd_step + ptsrc + taper_apply + trace sample)
+    FDW_MODE_MOD = 4,    // forward-modelling step of the CPU-serial sibling (mod_main: fd_step + ptsrc + taper_apply + trace sample)
+    FDW_MODE_DD_FWD = 5, // its stored-wavefield RTM, source pass (rtm_main.cpp:165-184: fd_step + one-cell source + taper_apply2)
+    FDW_MODE_DD_RECV = 6 // its receiver pass (rtm_main.cpp:197-220) + img += stored source field * CURRENT receiver field (rtm_main.cpp:224-230)
 };
 
 constexpr int kMaxFastHalfOrder = 4;   // register-window kernel is instantiated for order 2,4,6,8

@@ -481,8 +481,10 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
                 }
             }
             if constexpr (IMG) {
+                // kernel_img (R:133-144) correlates with the NEW receiver field; the sibling's rtm_main stores the CURRENT one
+                // (rwf[it] = P, rtm_main.cpp:211-215), an interior point of which carries damping factors of exactly 1.0f
 #pragma unroll
-                for (int e = 0; e < 4; ++e) imr.v[e] = qim[Q].v[e] + qps[Q].v[e] * res.v[e];
+                for (int e = 0; e < 4; ++e) imr.v[e] = qim[Q].v[e] + qps[Q].v[e] * (DD ? c.v[e] : res.v[e]);
             }
 #if FDW_ABL_BITS & (4 | 32)
             if (res.v[0] == 123.456f)
@@ -1169,6 +1171,8 @@ static hipError_t launch_fast_hp(const StepArgs& a, int mode, hipStream_t s)
     case FDW_MODE_RECV:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, PF>), grid, block, 0, s, a); break;
     case FDW_MODE_LAP:   hipLaunchKernelGGL((fdw_step_kernel<H, false, 0, false, true, PF>), grid, block, 0, s, a); break;
     case FDW_MODE_MOD:   hipLaunchKernelGGL((fdw_step_kernel<H, true, 3, false, false, PF, true>), grid, block, 0, s, a); break;
+    case FDW_MODE_DD_FWD:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 1, false, false, PF, true>), grid, block, 0, s, a); break;
+    case FDW_MODE_DD_RECV: hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, PF, true>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

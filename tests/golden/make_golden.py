@@ -15,6 +15,8 @@ oracle/Makefile from cuda_reference_RTM/lib/src/functions.c).  No reference sour
   dd_3lay_mod_vp_151x151.f32  dpct_gpu_rtm_domain_division/build/3lay_mod/3layer_151x151.bin (velocity model of the CPU-serial sibling)
   dd_3lay_mod_dobs.f32        dpct_gpu_rtm_domain_division/build/3lay_mod/dobs.bin: the gather its mod_main produced from that
                               model and decks/dd_3lay_mod.dat (151 traces x 1001 samples) -- known answer of the modelling producer
+  dd_3lay_mod_dir_image.f32   dpct_gpu_rtm_domain_division/build/3lay_mod/dir.image: the image its rtm_main formed from that gather
+                              (151x151; with ns = 1 the per-shot dir.img is the same bytes) -- known answer of the stored-wavefield RTM
 """
 import ctypes as C
 import os
@@ -46,6 +48,7 @@ def main():
         cp(src, os.path.join("decks", name))
     cp("dpct_gpu_rtm_domain_division/build/3lay_mod/3layer_151x151.bin", "dd_3lay_mod_vp_151x151.f32")
     cp("dpct_gpu_rtm_domain_division/build/3lay_mod/dobs.bin", "dd_3lay_mod_dobs.f32")
+    cp("dpct_gpu_rtm_domain_division/build/3lay_mod/dir.image", "dd_3lay_mod_dir_image.f32")
 
     L = O.ref_lib()
     assert L is not None, "build oracle/_ref first (make -C oracle)"

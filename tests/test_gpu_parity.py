@@ -593,3 +593,39 @@ def test_model_dialect_guards():
     with pytest.raises(F.FdwError):
         F.FDWave(10, 80, 70, 10, 10, 10, 0.02, 10.0, 10.0, 0.001, dialect=1)  # no generic-order modelling kernel
     assert ctx.steps_per_pass() == 1
+
+
+# ---- stored-wavefield RTM of the CPU-serial sibling (dialect RTM_STORED) --------------------------------
+def test_rtm_stored_shot_reproduces_the_reference_image_bit_exact():
+    """fdw_rtm_stored_shot on the sibling's own deck, model and gather (build/3lay_mod): its committed dir.image, bit for bit."""
+    from test_oracle_golden import dd_3lay_mod
+    d = dd_3lay_mod()
+    nxe, nze = d["nx"] + 2 * d["nxb"], d["nz"] + 2 * d["nzb"]
+    v2 = F.mod_extendvel(d["v2"], d["nx"], d["nz"], d["nxb"], d["nzb"])
+    srce = F.mod_ricker_wavelet(d["nt"], d["dt"], d["fpeak"])
+    ctx = F.FDWave(d["order"], nxe, nze, d["nxb"], d["nzb"], d["nt"], d["fac"], d["dx"], d["dz"], d["dt"], dialect=2)
+    img = ctx.rtm_stored_shot(v2, d["sx"], d["sz"], d["gz"], srce, d["dobs"])
+    assert_bit_equal(img, golden_field("dd_3lay_mod_dir_image.f32", (d["nx"], d["nz"])), "HIP rtm_stored_shot vs build/3lay_mod/dir.image")
+
+
+@pytest.mark.parametrize("case", [(61, 47, 13, 13, 50, 8, 10.0, 10.0, 0.02), (90, 300, 9, 9, 30, 8, 8.0, 12.5, 0.05), (50, 44, 7, 7, 30, 4, 10.0, 10.0, 0.03),
+                                  (64, 40, 12, 6, 25, 8, 10.0, 10.0, 0.03)], ids=lambda c: "x".join(map(str, c[:6])))
+def test_rtm_stored_shot_vs_oracle_bit_exact(case):
+    """Two shots of a random gather (the second one reads past its last trace, which counts as zero), unequal borders (the
+    reference's nzb row offset for the receivers), several strips, order 4."""
+    nx, nz, nxb, nzb, nt, order, dx, dz, fac = case
+    nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+    rng = np.random.default_rng(nx + 7 * nz)
+    vp = (1500 + 2500 * rng.random((nx, nz))).astype(np.float32)
+    v2 = np.zeros((nxe, nze), np.float32)
+    v2[nxb:nxb + nx, nzb:nzb + nz] = vp * vp
+    v2 = F.mod_extendvel(v2, nx, nz, nxb, nzb)
+    srce = (F.mod_ricker_wavelet(nt, 0.001, 40.0) + 0.1 * rng.standard_normal(nt)).astype(np.float32)
+    dobs = rng.standard_normal((2, nx, nt)).astype(np.float32)
+    ctx = F.FDWave(order, nxe, nze, nxb, nzb, nt, fac, dx, dz, 0.001, dialect=2)
+    for shot in (0, 1):
+        sx, sz, gz = nxb + 3 + 10 * shot, nzb + 1, nzb + 2
+        got = ctx.rtm_stored_shot(v2, sx, sz, gz, srce, dobs, shot=shot)
+        want = O.rtm_stored_shot(order, nx, nz, nxb, nzb, dx, dz, 0.001, fac, v2, sx, sz, gz, srce, dobs, shot=shot)
+        assert np.abs(want).max() > 0
+        assert_bit_equal(got, want, f"image of shot {shot}")

@@ -178,3 +178,30 @@ def test_modelling_passes_match_the_reference_functions():
         assert_bit_equal(pp, pp_ref, f"fd_step order {order}")
         R._Z10fd_destroyv()
     R._Z13taper_destroyv()
+
+
+def test_stored_wavefield_rtm_known_answer_bit_exact():
+    """oracle restatement of the sibling's rtm_main against its committed image build/3lay_mod/dir.image."""
+    d = dd_3lay_mod()
+    v2 = O.mod_extendvel(d["v2"], d["nx"], d["nz"], d["nxb"], d["nzb"])
+    srce = O.mod_ricker_wavelet(d["nt"], d["dt"], d["fpeak"])
+    img = O.rtm_stored_shot(d["order"], d["nx"], d["nz"], d["nxb"], d["nzb"], d["dx"], d["dz"], d["dt"], d["fac"], v2, d["sx"], d["sz"], d["gz"], srce, d["dobs"])
+    assert_bit_equal(img, golden_field("dd_3lay_mod_dir_image.f32", (d["nx"], d["nz"])), "oracle rtm_main loop vs build/3lay_mod/dir.image")
+
+
+def test_taper_apply2_matches_the_reference_function():
+    import ctypes as C
+    R = O.ref_dd_lib()
+    if R is None:
+        pytest.skip("oracle/_ref/libref_dd.so not built (reference tree absent)")
+    rng = np.random.default_rng(5)
+    nx, nz, nxb, nzb = 37, 29, 9, 7
+    fp = C.POINTER(C.c_float)
+    R._Z10taper_initiif(nxb, nzb, C.c_float(0.05))
+    a = rng.standard_normal((nx + 2 * nxb, nz + 2 * nzb)).astype(np.float32)
+    b = a.copy()
+    R._Z12taper_apply2PPfiiii((fp * a.shape[0])(*[C.cast(a[i].ctypes.data, fp) for i in range(a.shape[0])]), nx, nz, nxb, nzb)
+    tx, tz = O.mod_taper_tables(nxb, nzb, 0.05)
+    O.lib().orc_mod_taper_apply2(b, nx, nz, nxb, nzb, np.ascontiguousarray(tx), np.ascontiguousarray(tz))
+    assert_bit_equal(b, a, "taper_apply2")
+    R._Z13taper_destroyv()

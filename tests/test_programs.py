@@ -74,7 +74,7 @@ def test_deck_reader_details(tmp_path):
 
 
 def test_programs_are_built_and_refuse_bad_usage():
-    for exe in ("stencil_code", "rtm_code", "mod_main"):
+    for exe in ("stencil_code", "rtm_code", "mod_main", "rtm_main"):
         path = os.path.join(BIN, exe)
         assert os.access(path, os.X_OK), f"{path} missing: run `make -C parallel_finite_difference_computation_amd/csrc`"
         assert subprocess.run([path], capture_output=True).returncode != 0
@@ -333,3 +333,18 @@ def test_modelled_gather_feeds_the_rtm_program(tmp_path):
     assert r.returncode == 0, r.stderr + r.stdout
     img = np.fromfile(tmp_path / "out" / "dir.image", np.float32).reshape(nx, nz)
     assert np.isfinite(img).all() and np.abs(img).max() > 0
+
+
+@pytest.mark.gpu
+def test_rtm_main_program_reproduces_the_reference_image(tmp_path):
+    """The sibling's whole workflow on its own 3lay_mod deck: ./mod_main writes dobs.bin, ./rtm_main migrates it; dir.image and
+    dir.img are its committed images byte for byte."""
+    shutil.copy(os.path.join(GOLDEN, "dd_3lay_mod_vp_151x151.f32"), tmp_path / "3layer_151x151.bin")
+    shutil.copy(os.path.join(DECKS, "dd_3lay_mod.dat"), tmp_path / "input.dat")
+    for exe in ("mod_main", "rtm_main"):
+        r = subprocess.run([os.path.join(BIN, exe), "par=input.dat"], cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr + r.stdout
+    assert "** backward propagation 1, at (0,0) " in r.stdout and "Execution Time:" in r.stdout
+    gold = open(os.path.join(GOLDEN, "dd_3lay_mod_dir_image.f32"), "rb").read()
+    assert (tmp_path / "dir.image").read_bytes() == gold
+    assert (tmp_path / "dir.img").read_bytes() == gold          # one shot: the per-shot image is the stack
