@@ -529,7 +529,7 @@ static int step2_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
 // ---- kPipeSteps time steps per pass (wave pipeline through LDS) -------------------------------------
 static bool pipe_pays(const fdw_ctx* c)
 {
-    if (c->h != kMaxFastHalfOrder || c->use_generic || c->tb < 0 || c->prm.dialect != FDW_DIALECT_RTM) return false;
+    if (c->h != kMaxFastHalfOrder || c->use_generic || c->tb < 0 || c->prm.dialect == FDW_DIALECT_RTM_STORED) return false;
     if ((size_t)c->nxl * c->pitch * sizeof(float) >= (1ull << 31)) return false;   // the kernel addresses a field through one 2 GiB buffer descriptor
     if (c->tb == kPipeSteps) return true;
     if (c->tb > 0) return false;                                   // two-step forced
@@ -542,10 +542,12 @@ struct RowRanges {      // rows the pass produces: [r0, r1) and optionally [r0b,
     int r0 = 0, r1 = -1, r0b = 0, r1b = 0, xchunk = 0;
 };
 static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp, const float* d_v2, float* d_out1, float* d_out2, int pp_twice,
-                      const float* d_inj, int inj_x_global, int inj_z, hipStream_t s, const RowRanges& rr = RowRanges{})
+                      const float* d_inj, int inj_x_global, int inj_z, hipStream_t s, const RowRanges& rr = RowRanges{}, float* d_rec = nullptr,
+                      int rec_z = 0)
 {
     if (c->h != kMaxFastHalfOrder) return fail(FDW_EINVAL, "stepn: the pipelined kernel is built for order 8 only");
-    if (mode != FDW_MODE_FWD && mode != FDW_MODE_PLAIN) return fail(FDW_EINVAL, "stepn: FWD or PLAIN only");
+    if (mode != FDW_MODE_FWD && mode != FDW_MODE_PLAIN && mode != FDW_MODE_MOD) return fail(FDW_EINVAL, "stepn: FWD, PLAIN or MOD only");
+    if ((mode == FDW_MODE_MOD) != (c->prm.dialect == FDW_DIALECT_MOD)) return fail(FDW_ESTATE, "stepn: mode %d does not belong to dialect %d", mode, c->prm.dialect);
     if (!d_p || !d_pp || !d_v2 || !d_out1 || !d_out2) return fail(FDW_EINVAL, "stepn: NULL buffer");
     if (d_out1 == d_p || d_out1 == d_pp || d_out2 == d_p || d_out2 == d_pp || d_out1 == d_out2)
         return fail(FDW_EINVAL, "stepn: outputs must not alias the inputs (tiles re-read each other's input rows)");
@@ -568,6 +570,17 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
         a.inj_x = inj_x_global - c->slab.x_off;
         if (a.inj_x >= c->upd_x1 && a.inj_x < c->nxl)
             return fail(FDW_EINVAL, "stepn: source row %d lies in rows the reference never time-steps (>= %d)", inj_x_global, c->xlim);
+    }
+    if (mode == FDW_MODE_MOD) {
+        if (d_inj) {
+            if (inj_z < 0 || inj_z >= c->prm.nze || inj_x_global < 0 || inj_x_global >= c->prm.nxe)
+                return fail(FDW_EINVAL, "stepn: source (%d,%d) outside the grid", inj_x_global, inj_z);
+            a.inj_x = inj_x_global - c->slab.x_off;
+        }
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) a.gw[i][j] = expf(-(float)(i * i) - (float)(j * j));
+        a.dx2inv = c->dx2inv; a.dz2inv = c->dz2inv;
+        a.rec = d_rec; a.rec_z = rec_z; a.rec_x0 = c->prm.nxb - c->slab.x_off; a.rec_n = c->nx;
     }
     a.dt2 = c->dt2;
     for (int io = 0; io <= 2 * kMaxFastHalfOrder; io++) { a.cx[io] = c->cx[io]; a.cz[io] = c->cz[io]; }
@@ -968,7 +981,38 @@ extern "C" int fdw_dev_model_steps(fdw_ctx* c, float* d_p, float* d_pp, const fl
     if (!c) return fail(FDW_EINVAL, "ctx is NULL");
     if (c->prm.dialect != FDW_DIALECT_MOD) return fail(FDW_ESTATE, "fdw_dev_model_steps needs a context created with dialect = FDW_DIALECT_MOD");
     hipStream_t s = pick_stream(c, stream);
-    for (int k = 0; k < nsteps; k++) {
+    int k = 0;
+    if (pipe_pays(c) && nsteps >= kPipeSteps) {
+        // four steps per pass, out of place: the caller's two buffers plus two of the context's rotate.  In M's convention P is
+        // the current field; a pass reads (p = P, pp = PP) and leaves PP' = u^{n+3} in out1, P' = u^{n+4} in out2.
+        int rc = ensure_work_buffers(c, 4, false);
+        if (rc) return rc;
+        float* B[4] = {d_p, d_pp, c->fld[2], c->fld[3]};
+        int iP = 0, iPP = 1;
+        for (; nsteps - k >= kPipeSteps; k += kPipeSteps) {
+            int o1 = -1, o2 = -1;
+            for (int i = 0; i < 4; i++)
+                if (i != iP && i != iPP) { (o1 < 0 ? o1 : o2) = i; }
+            const int it = it0 + k;
+            rc = stepn_impl(c, FDW_MODE_MOD, B[iP], B[iPP], d_v2, B[o1], B[o2], 1, d_srce ? d_srce + it : nullptr, sx, sz, s, RowRanges{},
+                            d_rec ? d_rec + (size_t)it * c->nx : nullptr, gz);
+            if (rc) return rc;
+            iPP = o1; iP = o2;
+        }
+        // hand the state back in the caller's buffers: an even number of M's swaps leaves P in d_p and PP in d_pp
+        const size_t bytes = field_elems(c) * sizeof(float);
+        auto move = [&](int dst, int src) { return hipMemcpyAsync(B[dst], B[src], bytes, hipMemcpyDeviceToDevice, s); };
+        if (iP == 1 && iPP == 0) {            // crossed: go through a context buffer (both are free here)
+            HIP_TRY(move(2, 0)); HIP_TRY(move(0, 1)); HIP_TRY(move(1, 2));
+        } else if (iPP == 0) {                // PP sits where P must go: B[1] is free, clear B[0] first
+            HIP_TRY(move(1, 0));
+            HIP_TRY(move(0, iP));
+        } else {                              // B[0] is free or already holds P
+            if (iP != 0) HIP_TRY(move(0, iP));
+            if (iPP != 1) HIP_TRY(move(1, iPP));
+        }
+    }
+    for (; k < nsteps; k++) {
         const int it = it0 + k;
         int rc = step_impl(c, FDW_MODE_MOD, d_p, d_pp, d_v2, 0, c->nxl, 1, d_srce ? d_srce + it : nullptr, sx, sz, nullptr, nullptr, s,
                            d_rec ? d_rec + (size_t)it * c->nx : nullptr, gz);

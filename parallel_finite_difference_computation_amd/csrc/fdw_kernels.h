@@ -73,6 +73,11 @@ struct Step2Args {
     int xchunk, nstrip, nzblk, nblk, nper;
     float dt2;
     float cx[2 * kMaxFastHalfOrder + 1], cz[2 * kMaxFastHalfOrder + 1];
+    // pipeline kernel in FDW_MODE_MOD only (see StepArgs): unscaled weights in cz, spacings, Gaussian source weights, trace samples
+    float dx2inv, dz2inv;
+    float gw[4][4];
+    float* rec;            // [steps of the pass][rec_n]: wave k writes row k
+    int rec_z, rec_x0, rec_n;
 };
 hipError_t launch_step2(const Step2Args& a, int half_order, int mode, hipStream_t s);
 

@@ -870,7 +870,7 @@ __device__ __forceinline__ void f4_store_arr(__amdgpu_buffer_rsrc_t rs, unsigned
 #endif
 constexpr int kFifoRows = 16;   // v2 FIFO depth: > (NS-1)(H+1) for NS = 4, H = 4
 
-template <int H, int NS, bool TAPER, int INJ, int PF>
+template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false>
 __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const int k, const int cs, const int xa, const int xe,
                                        f4 (*link)[2][2][64], f4 (*fifo)[64])
 {
@@ -895,8 +895,10 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
     const bool wave_tap = TAPER && (cs * 4 < a.ztap);
     const bool xtap = wave_tap && ((xa - NS * H < a.xt_lo) || (xe + NS * H > a.xt_hi));
     const CoefPairs<H> cpk = coef_pairs<H>(a.cx, a.cz);
-    const bool inj_here = (INJ == 1) && (a.inj_z >= cs * 4) && (a.inj_z < cs * 4 + 256) && (a.inj_x >= xa - NS * H) && (a.inj_x < xe + NS * H);
+    const int blob = (INJ == 3) ? 3 : 0;                                  // INJ 3: 7x7 Gaussian source of the CPU-serial sibling (ptsrc.c:49-55)
+    const bool inj_here = (INJ != 0) && (a.inj_z + blob >= cs * 4) && (a.inj_z - blob < cs * 4 + 256) && (a.inj_x + blob >= xa - NS * H) && (a.inj_x - blob < xe + NS * H);
     const float injv = inj_here ? sload(a.inj, k) : 0.0f;                 // source sample of this wave's time step (R:119-122)
+    const bool rec_here = DD && (a.rec != nullptr) && (a.rec_z >= cs * 4) && (a.rec_z < cs * 4 + 256);
 
     bool mlap[4], mupd[4], znc[4], ihit[4];
     float tzc[4];
@@ -1004,7 +1006,27 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         const bool rowok = (r >= a.lap_x0) && (r < a.lap_x1);
         const bool rowupd = (r >= 0) && (r < a.upd_x1);
         f4 u;
-        {
+        if constexpr (DD) {
+            // this wave's p field is P of iteration it0 + k: its trace sample (mod_main.cpp:155-157); owned lanes and rows only
+            if (rec_here && own && r >= xa && r < xe && r >= a.rec_x0 && r < a.rec_x0 + a.rec_n) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (z0 + e == a.rec_z) a.rec[k * a.rec_n + (r - a.rec_x0)] = c1.v[e];
+            }
+            float W[12];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { W[e] = lft.v[e]; W[4 + e] = c1.v[e]; W[8 + e] = rgt.v[e]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float col[2 * H + 1];
+#pragma unroll
+                for (int io = 0; io <= 2 * H; ++io) col[io] = ring[(U + io) % R].v[e];
+                float lap = laplacian_dd_pt<H>(W, e, col, a.cz, a.dx2inv, a.dz2inv);
+                lap = (rowok && mlap[e]) ? lap : 0.0f;
+                const float upd = leapfrog_prod(c1.v[e], ppt.v[e], (v2t.v[e] * a.dt2) * lap);
+                u.v[e] = (rowupd && mupd[e]) ? upd : ppt.v[e];
+            }
+        } else {
             const ZPairs zp = zpairs(lft, c1, rgt);
             static_for<2>([&](auto PP) {
                 constexpr int P = decltype(PP)::value;
@@ -1032,6 +1054,18 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
                 for (int e = 0; e < 4; ++e) u.v[e] = ihit[e] ? u.v[e] + injv : u.v[e];
             }
         }
+        if constexpr (INJ == 3) {
+            if (inj_here && r >= a.inj_x - 3 && r <= a.inj_x + 3) {
+                const int dxa = r > a.inj_x ? r - a.inj_x : a.inj_x - r;
+                const float g0 = a.gw[dxa][0], g1 = a.gw[dxa][1], g2 = a.gw[dxa][2], g3 = a.gw[dxa][3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int dz = z0 + e - a.inj_z, dza = dz < 0 ? -dz : dz;
+                    const float g = dza == 0 ? g0 : (dza == 1 ? g1 : (dza == 2 ? g2 : g3));
+                    if (dza <= 3) u.v[e] = u.v[e] + injv * g;
+                }
+            }
+        }
         // ---- hand over to the next wave: the new row (raw) and the row leaving this window (damped once) ----
 #if !(FDW_ABL_BITS & 128)
         link[k][par][0][lane] = u;
@@ -1056,7 +1090,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         static_for<R>([&](auto UU) { row_step(mb, UU); });
 }
 
-template <int H, int NS, bool TAPER, int INJ, int PF>
+template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false>
 __global__ __launch_bounds__(64 * NS, 4) void fdw_stepn_kernel(const Step2Args a)
 {
     const int lane = threadIdx.x & 63;
@@ -1072,7 +1106,7 @@ __global__ __launch_bounds__(64 * NS, 4) void fdw_stepn_kernel(const Step2Args a
     if (xa >= xe) return;
     __shared__ f4 link[NS][2][2][64];           // [producer wave][parity of m][0 new row | 1 row leaving the window][lane]
     __shared__ f4 fifo[kFifoRows][64];
-    marchn<H, NS, TAPER, INJ, PF>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo);
+    marchn<H, NS, TAPER, INJ, PF, DD>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1218,6 +1252,7 @@ hipError_t launch_stepn(const Step2Args& a, int h, int mode, hipStream_t s)
     switch (mode) {
     case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 1, FDW_PIPE_PF>), grid, block, 0, s, a); break;
     case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, false, 0, FDW_PIPE_PF>), grid, block, 0, s, a); break;
+    case FDW_MODE_MOD:   hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 3, FDW_PIPE_PF, true>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

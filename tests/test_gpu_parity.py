@@ -549,6 +549,10 @@ def test_model_shot_reproduces_the_reference_gather_bit_exact():
     for xchunk in (1, 7):
         ctx.set_tuning(xchunk=xchunk)
         assert_bit_equal(ctx.model_shot(v2, d["sx"], d["sz"], d["gz"], srce), d["dobs"], f"xchunk={xchunk}")
+    for xchunk in (0, 13):                     # four steps per pass through the wave pipeline (1001 = 250 passes + 1 step)
+        ctx.set_tuning(xchunk=xchunk, two_step=4)
+        assert ctx.steps_per_pass() == 4
+        assert_bit_equal(ctx.model_shot(v2, d["sx"], d["sz"], d["gz"], srce), d["dobs"], f"pipeline xchunk={xchunk}")
 
 
 MOD_CASES = [
@@ -579,6 +583,10 @@ def test_model_shot_vs_oracle_bit_exact(case):
     want = O.mod_shot(order, nx, nz, nxb, nzb, dx, dz, 0.001, fac, v2, sx0 + nxb, sz0 + nzb, gz0 + nzb, srce)
     assert np.abs(want).max() > 0
     assert_bit_equal(got, want, "gather")
+    if order == 8:                              # the same through the four-steps-per-pass wave pipeline, two chunk lengths, odd step counts
+        for xchunk, n in ((0, nt), (7, nt - 1), (13, nt - 3)):
+            ctx.set_tuning(xchunk=xchunk, two_step=4)
+            assert_bit_equal(ctx.model_shot(v2, sx0 + nxb, sz0 + nzb, gz0 + nzb, srce[:n]), want[:, :n], f"pipeline gather xchunk={xchunk} nt={n}")
 
 
 def test_model_dialect_guards():
