@@ -230,6 +230,25 @@ __device__ __forceinline__ v2f laplacian_pair(const ZPairs& z, Col&& col, const 
     return acmz + acmx;
 }
 __device__ __forceinline__ v2f f4_pair(const f4& a, int P) { return v2f{a.v[2 * P], a.v[2 * P + 1]}; }
+// Both pairs of a lane at once: the four accumulator chains (z and x of each pair) advance tap by tap side by side, which gives a
+// lone wave four independent dependency chains to issue from instead of two (same operations, same order within each chain).
+template <int H, class Row>
+__device__ __forceinline__ void laplacian_quad(const ZPairs& z, Row&& row, const CoefPairs<H>& c, v2f& lap01, v2f& lap23)
+{
+    v2f az0 = {0.0f, 0.0f}, ax0 = {0.0f, 0.0f}, az1 = {0.0f, 0.0f}, ax1 = {0.0f, 0.0f};
+    static_for<2 * H + 1>([&](auto IO) {
+        constexpr int io = decltype(IO)::value;
+        constexpr int k0 = 4 - H + io, k1 = 6 - H + io;
+        constexpr int ic = io <= H ? io : 2 * H - io;
+        const f4 r = row(IO);
+        az0 = az0 + pk_mul_sel<ic & 1>((k0 & 1) ? z.O[k0 >> 1] : z.E[k0 >> 1], c.z[ic >> 1]);
+        ax0 = ax0 + pk_mul_sel<ic & 1>(v2f{r.v[0], r.v[1]}, c.x[ic >> 1]);
+        az1 = az1 + pk_mul_sel<ic & 1>((k1 & 1) ? z.O[k1 >> 1] : z.E[k1 >> 1], c.z[ic >> 1]);
+        ax1 = ax1 + pk_mul_sel<ic & 1>(v2f{r.v[2], r.v[3]}, c.x[ic >> 1]);
+    });
+    lap01 = az0 + ax0;
+    lap23 = az1 + ax1;
+}
 
 // ring geometry: PF rows of pointwise look-ahead (pp, v2, halo, ...); the p ring holds R rows,
 // R a multiple of PF (so queue slots are compile-time constants) and >= 2H+PF.
@@ -868,18 +887,30 @@ __device__ __forceinline__ void f4_store_arr(__amdgpu_buffer_rsrc_t rs, unsigned
 #ifndef FDW_PIPE_PF
 #define FDW_PIPE_PF 2      // rows of global look-ahead of wave 0
 #endif
-constexpr int kFifoRows = 16;   // v2 FIFO depth: > (NS-1)(H+1) for NS = 4, H = 4
-
-template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false>
-__device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const int k, const int cs, const int xa, const int xe,
-                                       f4 (*link)[2][2][64], f4 (*fifo)[64])
+#ifndef FDW_PIPE_ROWS
+#define FDW_PIPE_ROWS 1    // march steps between two workgroup barriers of the pipeline kernel (1 or 2)
+#endif
+// v2 FIFO depth: the last wave reads row m - (NS-1)(H+ROWS) while wave 0 writes rows m .. m+ROWS-1
+constexpr int pipe_fifo_rows(int ns, int h, int rows) { return rows == 1 ? 16 : (ns - 1) * (h + rows) + rows; }
+template <int FD>
+__device__ __forceinline__ int pipe_fifo_slot(int m)
 {
-    static_assert((NS - 1) * (H + 1) < kFifoRows, "v2 FIFO too short");
+    if constexpr ((FD & (FD - 1)) == 0) return m & (FD - 1);
+    else return ((m % FD) + FD) % FD;
+}
+
+template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int ROWS = FDW_PIPE_ROWS>
+__device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const int k, const int cs, const int xa, const int xe,
+                                       f4 (*link)[2][2][ROWS][64], f4 (*fifo)[64])
+{
+    // ROWS march steps between two workgroup barriers (1 or 2): a wave consumes what its predecessor produced during the previous
+    // ROWS steps, so consecutive waves work H + ROWS rows apart and a wave's first good row comes ROWS later per stage.
     constexpr int R = ((2 * H + PF + PF - 1) / PF) * PF;
     constexpr int LOOK = R - 2 * H;
-    constexpr int SK = H + 1;
+    constexpr int SK = H + ROWS;
+    constexpr int FD = pipe_fifo_rows(NS, H, ROWS);
+    static_assert(ROWS == 1 || (ROWS == 2 && R % 2 == 0), "one or two rows per barrier");
     const bool first = (k == 0);
-    static_assert(R % 2 == 0, "link parity is taken from the unroll index");
     const int cell = cs + lane;
     const int z0 = cell * 4;
     const unsigned voff = (unsigned)min(max(z0, 0), a.pitch - 4) * 4u;
@@ -935,7 +966,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
     // rows: wave 0's centre row at march step m is s0 + m (what the global loads follow); this wave's is rk + m
     const int s0 = xa - (NS - 1) * H, b0 = s0 - H;
     const int rk = s0 - k * SK;
-    const int M = (xe - xa) + (NS - 1) * (2 * H + 1);
+    const int M = (xe - xa) + (NS - 1) * (2 * H + ROWS);
     const int kp = max(k - 1, 0);
     f4 ring[R];
     f4 qpp[PF], qv2[PF];
@@ -968,14 +999,15 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         constexpr int E = (U + 2 * H) % R;                      // slot of the row entering the window this step
         const int m = mb + U;
         const int r = rk + m;
-        constexpr int par = U & 1;                               // == m & 1: R is even
+        constexpr int SLOT = U % ROWS;                          // which of the ROWS rows between two barriers
+        const int par = (m / ROWS) & 1;                          // link buffers alternate per barrier interval
         // ---- what the previous wave handed over during march step m-1 ----
 #if FDW_ABL_BITS & 128
         const f4 nr = ring[U], ppl = ring[(U + 1) % R], v2l = ring[(U + 2) % R];
 #else
-        const f4 nr = link[kp][par ^ 1][0][lane];
-        const f4 ppl = link[kp][par ^ 1][1][lane];
-        const f4 v2l = fifo[(m - k * SK) & (kFifoRows - 1)][lane];
+        const f4 nr = link[kp][par ^ 1][0][SLOT][lane];
+        const f4 ppl = link[kp][par ^ 1][1][SLOT][lane];
+        const f4 v2l = fifo[pipe_fifo_slot<FD>(m - k * SK)][lane];
 #endif
         f4 ppt, v2t;
 #pragma unroll
@@ -985,7 +1017,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             v2t.v[e] = first ? qv2[Q].v[e] : v2l.v[e];
         }
 #if !(FDW_ABL_BITS & 128)
-        if (first) fifo[m & (kFifoRows - 1)][lane] = qv2[Q];
+        if (first) fifo[pipe_fifo_slot<FD>(m)][lane] = qv2[Q];
 #endif
         if (wave_tap) {
             taper_row(ring[E], r + H);                          // entering row: damped once as "p" of this step
@@ -1028,22 +1060,16 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             }
         } else {
             const ZPairs zp = zpairs(lft, c1, rgt);
+            v2f lapq[2];
+            laplacian_quad<H>(zp, [&](auto IO) -> const f4& { return ring[(U + decltype(IO)::value) % R]; }, cpk, lapq[0], lapq[1]);
             static_for<2>([&](auto PP) {
                 constexpr int P = decltype(PP)::value;
-#if FDW_ABL_BITS & 256
-                const v2f lap2 = zp.E[P] + zp.O[P + 2] + f4_pair(ring[U], P) + f4_pair(ring[(U + 2 * H) % R], P);
-#else
-                const v2f lap2 = laplacian_pair<H, P>(zp, [&](auto IO) { return f4_pair(ring[(U + decltype(IO)::value) % R], P); }, cpk);
-#endif
+                const v2f lap2 = lapq[P];
                 const v2f prod2 = (f4_pair(v2t, P) * a.dt2) * v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int e = 2 * P + q;
-#if FDW_ABL_BITS & 512
-                    const float upd = (c1.v[e] + c1.v[e] - ppt.v[e]) + (q ? prod2.y : prod2.x);
-#else
                     const float upd = leapfrog_prod(c1.v[e], ppt.v[e], q ? prod2.y : prod2.x);
-#endif
                     u.v[e] = (rowupd && mupd[e]) ? upd : ppt.v[e];
                 }
             });
@@ -1068,8 +1094,8 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         }
         // ---- hand over to the next wave: the new row (raw) and the row leaving this window (damped once) ----
 #if !(FDW_ABL_BITS & 128)
-        link[k][par][0][lane] = u;
-        link[k][par][1][lane] = ring[U];
+        link[k][par][0][SLOT][lane] = u;
+        link[k][par][1][SLOT][lane] = ring[U];
 #endif
         const unsigned so = ((r >= xa) && (r < xe) && (m < M)) ? soff : kLaneOff;
 #if FDW_ABL_BITS & 1024
@@ -1082,7 +1108,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         qv2[Q] = load_pw(rs_v2, s0 + m + PF);
 #endif
 #if !(FDW_ABL_BITS & 64)
-        __syncthreads();
+        if constexpr (SLOT == ROWS - 1) __syncthreads();
 #endif
     };
 
@@ -1091,7 +1117,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
 }
 
 template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false>
-__global__ __launch_bounds__(64 * NS, 4) void fdw_stepn_kernel(const Step2Args a)
+__global__ __launch_bounds__(64 * NS, FDW_PIPE_ROWS != 1 ? 3 : (DD ? 4 : 5)) void fdw_stepn_kernel(const Step2Args a)
 {
     const int lane = threadIdx.x & 63;
     const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1104,8 +1130,8 @@ __global__ __launch_bounds__(64 * NS, 4) void fdw_stepn_kernel(const Step2Args a
     const int xa = second ? a.r0b + (xb - a.chunks_a) * a.xchunk : a.r0 + xb * a.xchunk;
     const int xe = min(xa + a.xchunk, second ? a.r1b : a.r1);
     if (xa >= xe) return;
-    __shared__ f4 link[NS][2][2][64];           // [producer wave][parity of m][0 new row | 1 row leaving the window][lane]
-    __shared__ f4 fifo[kFifoRows][64];
+    __shared__ f4 link[NS][2][2][FDW_PIPE_ROWS][64];       // [producer wave][parity][0 new row | 1 row leaving the window][row of the interval][lane]
+    __shared__ f4 fifo[pipe_fifo_rows(NS, H, FDW_PIPE_ROWS)][64];
     marchn<H, NS, TAPER, INJ, PF, DD>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo);
 }
 
