@@ -31,6 +31,32 @@ class OracleSlabStepper:
                            taper_rows=rows)
 
 
+class OraclePipeCtx:
+    """Test-only stand-in for the slab's FDWave context in SlabForward's four-steps-per-pass mode: dev_step4 on CPU tensors with the
+    oracle (four eager in-place steps on copies of the inputs, the requested rows copied out)."""
+
+    def __init__(self, orc, x_off, h, tensors, srce):
+        self.orc, self.x_off, self.h = orc, x_off, h
+        self.by_ptr = {t.data_ptr(): t for t in tensors}
+        self.srce = srce
+
+    def dev_step4(self, p, pp, v2, out1, out2, pp_twice=True, d_srce_it=None, sx=-1, sz=0, r0=0, r1=-1, r0b=0, r1b=0, xchunk=0, stream=None):
+        t = self.by_ptr
+        it = (d_srce_it - self.srce.data_ptr()) // 4 if d_srce_it is not None else None
+        nxl = t[p].shape[0]
+        for (a, b) in ((r0, nxl if r1 < 0 else r1), (r0b, r1b)):
+            if b <= a:
+                continue
+            dp, dpp = t[pp].numpy().copy(), t[p].numpy().copy()      # the reference's (d_p, d_pp) before its swap: d_pp is the newest
+            for j in range(1, 5):
+                dp, dpp = dpp, dp
+                lo, hi = max(0, a - self.h * (4 - j)), min(nxl, b + self.h * (4 - j))
+                val = float(self.srce[it + j - 1]) if it is not None else 0.0
+                self.orc.slab_step(self.x_off, dp, dpp, t[v2].numpy(), lo, hi, sx if it is not None else -1, sz, val)
+            t[out1].numpy()[a:b] = dp[a:b]
+            t[out2].numpy()[a:b] = dpp[a:b]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -39,7 +65,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, d, nsteps, ksteps, out):
+def _worker(rank, world, port, d, nsteps, ksteps, out, pipe=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -63,7 +89,13 @@ def _worker(rank, world, port, d, nsteps, ksteps, out):
             b[g.nxl - g.g_hi:] = -7.0
         v2 = torch.from_numpy(d["v2"][sl].copy())
         srce = torch.from_numpy(O.ricker_wavelet(d["nt"], d["dt"], 30.0))
-        fw = SlabForward(g, OracleSlabStepper(orc, g.x_off), (a, b), v2, srce, d["sx"], d["sz"])
+        if pipe:
+            spare = [torch.full_like(a, 3.0), torch.full_like(a, -3.0)]        # stale contents must not matter
+            fw = SlabForward(g, OracleSlabStepper(orc, g.x_off), (a, b, spare[0], spare[1]), v2, srce, d["sx"], d["sz"],
+                             pipe_ctx=OraclePipeCtx(orc, g.x_off, g.h, [a, b, spare[0], spare[1], v2], srce))
+            assert fw.pipe_ctx is not None
+        else:
+            fw = SlabForward(g, OracleSlabStepper(orc, g.x_off), (a, b), v2, srce, d["sx"], d["sz"])
         # the reference swaps before the first step: start with roles (d_p, d_pp) = (a, b)
         dp, dpp = fw.run(nsteps)
         np.save(out + f".p{rank}.npy", fw.owned(dp).numpy())
@@ -92,6 +124,25 @@ def test_slab_decomposition_matches_single_domain(tmp_path, world, ksteps, nstep
     gpp = np.concatenate([np.load(out + f".pp{r}.npy") for r in range(world)])
     assert_bit_equal(gpp, PP, "decomposed PP")
     assert_bit_equal(gp, P, "decomposed P")
+
+
+@pytest.mark.parametrize("world,ksteps,nsteps", [(2, 8, 16), (2, 4, 10), (3, 4, 12)])
+def test_slab_decomposition_four_steps_per_pass_matches_single_domain(tmp_path, world, ksteps, nsteps):
+    """SlabForward's pipeline mode (four rotating buffers, passes of four steps on shrinking row ranges, split last pass, leftover steps
+    through the one-step path) with the oracle standing in for fdw_dev_step4."""
+    nxe, nze, nt = 168, 40, 16
+    d = make_deck(nxe, nze, 17, 9, nt, seed=6, compat=False)
+    out = str(tmp_path / "slab4")
+    mp.start_processes(_worker, args=(world, _free_port(), d, nsteps, ksteps, out, True), nprocs=world, join=True, start_method="fork")
+    rng = np.random.default_rng(1)
+    p0 = (0.1 * rng.standard_normal((nxe, nze))).astype(np.float32)
+    pp0 = (0.1 * rng.standard_normal((nxe, nze))).astype(np.float32)
+    orc = O.Oracle(8, nxe, nze, 17, 9, nt, 0.75, 10.0, 10.0, 0.001, compat=False)
+    P, PP = orc.forward(d["v2"], d["sx"], d["sz"], O.ricker_wavelet(nt, 0.001, 30.0), p0, pp0, nsteps=nsteps)
+    gp = np.concatenate([np.load(out + f".p{r}.npy") for r in range(world)])
+    gpp = np.concatenate([np.load(out + f".pp{r}.npy") for r in range(world)])
+    assert_bit_equal(gpp, PP, "decomposed PP (pipeline mode)")
+    assert_bit_equal(gp, P, "decomposed P (pipeline mode)")
 
 
 def test_slab_step_single_slab_equals_forward():
