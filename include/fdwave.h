@@ -188,6 +188,12 @@ void fdw_mod_taper_tables(int nxb, int nzb, float fac, float *taper_x, float *ta
 int fdw_rtm_stored_shot(fdw_ctx *ctx, const float *vel2, int sx, int sz, int gz, const float *srce, int nt, const float *dobs,
                         size_t n_floats, int is, float *imloc);
 
+/* ---- image post-processing -----------------------------------------------------------------
+ * fdw_image_laplacian  the reference's offline filter models/3lay_mod/laplace.f90:25-29 (dir.image -> dir.imalap): second-order
+ *                 Laplacian of img[nx][nz] with the frame left at zero, on `device`.  (The reference's `psnr` comparer ships as a binary
+ *                 without source and is not restated.) */
+int fdw_image_laplacian(int device, const float *img, int nx, int nz, float dx, float dz, float *out);
+
 /* host <-> pitched device copies (dense [rows][nze] on the host side), synchronous */
 int fdw_upload_field(fdw_ctx *ctx, float *d_dst, const float *h_src);
 int fdw_download_field(fdw_ctx *ctx, float *h_dst, const float *d_src);

@@ -198,3 +198,20 @@ void orc_rtm_stored_shot(int order, int nx, int nz, int nxb, int nzb, int nt, fl
         for (size_t k = 0; k < ni; k++) imloc[k] += swf[(size_t)(nt - it - 1) * ni + k] * rwf[(size_t)it * ni + k];
     free(P); free(PP); free(lap); free(swf); free(rwf); free(taperx); free(taperz);
 }
+
+/* ======================================================================================================================
+ * Image post-processing: LP = dpct_gpu_rtm_domain_division/build/3lay_mod/laplace.f90 (the same file
+ * sits in cuda_reference_RTM/models/3lay_mod), a second-order Laplacian filter of dir.image -> dir.imalap.  LP:25-29, single precision,
+ * in the order the Fortran expression spells: ((a - 2*c) + b)/(dz*dz) + ((d - 2*c) + e)/(dx*dx); the frame stays 0.
+ * Pin: bit-exact against the program itself built with flang from that source and run on build/3lay_mod/dir.image.
+ * ====================================================================================================================== */
+void orc_image_laplacian(const float *img, int nx, int nz, float dx, float dz, float *out)
+{
+    memset(out, 0, (size_t)nx * nz * sizeof(float));
+    for (int ix = 1; ix < nx - 1; ix++)
+        for (int iz = 1; iz < nz - 1; iz++) {
+            const size_t k = (size_t)ix * nz + iz;
+            const float c = img[k];
+            out[k] = ((img[k + 1] - 2.f * c) + img[k - 1]) / (dz * dz) + ((img[k + nz] - 2.f * c) + img[k - nz]) / (dx * dx);
+        }
+}

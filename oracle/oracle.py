@@ -49,6 +49,7 @@ def lib():
         L.orc_mod_ptsrc.argtypes = [C.c_int] * 4 + [C.c_float, f32p]
         L.orc_mod_shot.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p]
         L.orc_mod_taper_apply2.argtypes = [f32p] + [C.c_int] * 4 + [f32p, f32p]
+        L.orc_image_laplacian.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p]
         L.orc_rtm_stored_shot.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_size_t, C.c_int, f32p]
         _LIB = L
     return _LIB
@@ -192,6 +193,20 @@ def rtm_stored_shot(order, nx, nz, nxb, nzb, dx, dz, dt, fac, vel2, sx, sz, gz, 
     lib().orc_rtm_stored_shot(order, nx, nz, nxb, nzb, srce.size, dx, dz, dt, fac, np.ascontiguousarray(vel2, np.float32), sx, sz, gz, srce,
                               dobs, dobs.size, shot, imloc)
     return imloc
+
+
+def image_laplacian(img, dx, dz):
+    """laplace.f90:25-29 on img[nx][nz]."""
+    img = np.ascontiguousarray(img, np.float32)
+    out = np.zeros_like(img)
+    lib().orc_image_laplacian(img, img.shape[0], img.shape[1], dx, dz, out)
+    return out
+
+
+def ref_lapfilt():
+    """Path of the reference's laplace.f90 built with flang (oracle/_ref/lapfilt); None when not built."""
+    exe = os.path.join(_HERE, "_ref", "lapfilt")
+    return exe if os.path.exists(exe) else None
 
 
 def ref_dd_lib():

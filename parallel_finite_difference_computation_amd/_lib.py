@@ -52,6 +52,7 @@ SIGNATURES = [
     ("fdw_dev_steps2", C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]),
     ("fdw_dev_taper_finalize", C.c_int, [vp, vp, vp]),
     ("fdw_model_shot", C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p]),
+    ("fdw_image_laplacian", C.c_int, [C.c_int, f32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p]),
     ("fdw_rtm_stored_shot", C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_size_t, C.c_int, f32p]),
     ("fdw_dev_model_steps", C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
     ("fdw_mod_extendvel", None, [C.c_int] * 4 + [f32p]),

@@ -75,6 +75,14 @@ def mod_taper_tables(nxb, nzb, fac):
     return tx[:nxb], tz[:nzb]
 
 
+def image_laplacian(img, dx, dz, device=0):
+    """The reference's offline image filter (models/3lay_mod/laplace.f90:25-29) on img[nx][nz]; runs on the GPU."""
+    img = np.ascontiguousarray(img, np.float32)
+    out = np.zeros_like(img)
+    check(lib().fdw_image_laplacian(device, img, img.shape[0], img.shape[1], dx, dz, out))
+    return out
+
+
 class FDWave:
     """One fd_init (fd-code.cu:200-224 / fd-source-code.cu:241-262) worth of state on one MI355X."""
 

@@ -1105,6 +1105,32 @@ extern "C" int fdw_rtm_stored_shot(fdw_ctx* c, const float* vel2, int sx, int sz
     return FDW_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// image post-processing (row f3): laplace.f90
+// ------------------------------------------------------------------------------------------------
+extern "C" int fdw_image_laplacian(int device, const float* img, int nx, int nz, float dx, float dz, float* out)
+{
+    if (!img || !out || nx < 1 || nz < 1 || !(dx > 0.0f) || !(dz > 0.0f)) return fail(FDW_EINVAL, "image_laplacian: bad argument");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || device < 0 || device >= ndev)
+        return fail(FDW_ENODEVICE, "image_laplacian: no HIP device %d (%s); libfdwave has no CPU path", device, e != hipSuccess ? hipGetErrorString(e) : "out of range");
+    HIP_TRY(hipSetDevice(device));
+    const size_t bytes = (size_t)nx * nz * sizeof(float);
+    float *d_in = nullptr, *d_out = nullptr;
+    if (hipMalloc((void**)&d_in, bytes) != hipSuccess || hipMalloc((void**)&d_out, bytes) != hipSuccess) {
+        if (d_in) (void)hipFree(d_in);
+        return fail(FDW_ENOMEM, "image_laplacian: hipMalloc(%zu) failed", bytes);
+    }
+    int rc = FDW_OK;
+    if ((e = hipMemcpy(d_in, img, bytes, hipMemcpyHostToDevice)) != hipSuccess || (e = launch_image_laplacian(d_in, d_out, nx, nz, dx, dz, nullptr)) != hipSuccess ||
+        (e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost)) != hipSuccess)
+        rc = fail(FDW_EHIP, "image_laplacian: %s", hipGetErrorString(e));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
 extern "C" int fdw_get_tables(const fdw_ctx* c, float* coefs_x, float* coefs_z, float* taper_x, float* taper_z)
 {
     if (!c) return fail(FDW_EINVAL, "ctx is NULL");

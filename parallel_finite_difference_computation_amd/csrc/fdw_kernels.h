@@ -92,5 +92,6 @@ hipError_t launch_step_generic(const StepArgs& a, int half_order, int mode, hipS
 hipError_t launch_taper_finalize(float* f, const float* taperz, const float* txfac, int pitch, int nxl, int ztap,
                                  int tz_x1, hipStream_t s);
 hipError_t launch_selftest(const float* src, float* out, hipStream_t s);
+hipError_t launch_image_laplacian(const float* d_img, float* d_out, int nx, int nz, float dx, float dz, hipStream_t s);
 
 }  // namespace fdw

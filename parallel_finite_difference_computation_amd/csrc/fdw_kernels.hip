@@ -1207,6 +1207,21 @@ __global__ __launch_bounds__(256) void fdw_taper_finalize_kernel(float* f, const
 //   out[128..383] = a 64 x float4 row written with the range-predicated buffer store: lanes 2..61 store at
 //                   their own offset, the others at 0xFFFFFFF0 and must be dropped by the descriptor check
 // ------------------------------------------------------------------------------------------------
+// Image post-processing: the second-order Laplacian filter of laplace.f90:25-29 on a dense [nx][nz] image, in the
+// order the Fortran expression spells, frame left at zero.  HBM bound and tiny (one read, one write per point).
+__global__ __launch_bounds__(256) void fdw_image_lap_kernel(const float* img, float* out, int nx, int nz, float dx, float dz)
+{
+    const int iz = blockIdx.x * 256 + threadIdx.x, ix = blockIdx.y;
+    if (iz >= nz) return;
+    const size_t k = (size_t)ix * nz + iz;
+    float r = 0.0f;
+    if (ix >= 1 && ix < nx - 1 && iz >= 1 && iz < nz - 1) {
+        const float c = img[k];
+        r = ((img[k + 1] - 2.0f * c) + img[k - 1]) / (dz * dz) + ((img[k + nz] - 2.0f * c) + img[k - nz]) / (dx * dx);
+    }
+    out[k] = r;
+}
+
 __global__ void fdw_selftest_kernel(const float* src, float* out)
 {
     const int t = threadIdx.x;
@@ -1301,6 +1316,12 @@ hipError_t launch_taper_finalize(float* f, const float* taperz, const float* txf
     if (ztap <= 0 || nxl <= 0) return hipSuccess;
     const dim3 grid((ztap + 255) / 256, nxl), block(256);
     hipLaunchKernelGGL(fdw_taper_finalize_kernel, grid, block, 0, s, f, taperz, txfac, pitch, nxl, ztap, tz_x1);
+    return hipGetLastError();
+}
+
+hipError_t launch_image_laplacian(const float* d_img, float* d_out, int nx, int nz, float dx, float dz, hipStream_t s)
+{
+    hipLaunchKernelGGL(fdw_image_lap_kernel, dim3((nz + 255) / 256, nx), dim3(256), 0, s, d_img, d_out, nx, nz, dx, dz);
     return hipGetLastError();
 }
 

@@ -17,6 +17,7 @@ oracle/Makefile from cuda_reference_RTM/lib/src/functions.c).  No reference sour
                               model and decks/dd_3lay_mod.dat (151 traces x 1001 samples) -- known answer of the modelling producer
   dd_3lay_mod_dir_image.f32   dpct_gpu_rtm_domain_division/build/3lay_mod/dir.image: the image its rtm_main formed from that gather
                               (151x151; with ns = 1 the per-shot dir.img is the same bytes) -- known answer of the stored-wavefield RTM
+  dd_3lay_mod_dir_imalap.f32  output of the reference's laplace.f90 (built unmodified with flang: oracle/_ref/lapfilt) run on that dir.image
 """
 import ctypes as C
 import os
@@ -49,6 +50,14 @@ def main():
     cp("dpct_gpu_rtm_domain_division/build/3lay_mod/3layer_151x151.bin", "dd_3lay_mod_vp_151x151.f32")
     cp("dpct_gpu_rtm_domain_division/build/3lay_mod/dobs.bin", "dd_3lay_mod_dobs.f32")
     cp("dpct_gpu_rtm_domain_division/build/3lay_mod/dir.image", "dd_3lay_mod_dir_image.f32")
+    lapfilt = O.ref_lapfilt()
+    assert lapfilt is not None, "build oracle/_ref/lapfilt first (make -C oracle)"
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:       # the program reads ./dir.image and writes ./dir.imalap (151x151 built in)
+        shutil.copyfile(os.path.join(HERE, "dd_3lay_mod_dir_image.f32"), os.path.join(td, "dir.image"))
+        subprocess.check_call([lapfilt], cwd=td)
+        shutil.copyfile(os.path.join(td, "dir.imalap"), os.path.join(HERE, "dd_3lay_mod_dir_imalap.f32"))
 
     L = O.ref_lib()
     assert L is not None, "build oracle/_ref first (make -C oracle)"

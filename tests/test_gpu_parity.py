@@ -637,3 +637,14 @@ def test_rtm_stored_shot_vs_oracle_bit_exact(case):
         want = O.rtm_stored_shot(order, nx, nz, nxb, nzb, dx, dz, 0.001, fac, v2, sx, sz, gz, srce, dobs, shot=shot)
         assert np.abs(want).max() > 0
         assert_bit_equal(got, want, f"image of shot {shot}")
+
+
+def test_image_laplacian_known_answer_and_oracle():
+    """Row f3: fdw_image_laplacian against the reference program's own output (laplace.f90 built with flang, run on the sibling's dir.image)
+    and against the oracle on a non-square random image with dx != dz."""
+    img = golden_field("dd_3lay_mod_dir_image.f32", (151, 151))
+    assert_bit_equal(F.image_laplacian(img, 10.0, 10.0), golden_field("dd_3lay_mod_dir_imalap.f32", (151, 151)), "HIP image Laplacian vs dir.imalap")
+    rnd = np.random.default_rng(2).standard_normal((37, 301)).astype(np.float32)
+    assert_bit_equal(F.image_laplacian(rnd, 8.0, 12.5), O.image_laplacian(rnd, 8.0, 12.5), "random image")
+    one = np.ones((1, 5), np.float32)
+    assert not F.image_laplacian(one, 1.0, 1.0).any()

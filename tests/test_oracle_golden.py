@@ -1,5 +1,7 @@
 """CPU: the oracle (oracle/fdw_oracle.c) against every known answer the reference ships.
 This is what pins the oracle; the GPU tests then compare the HIP path with the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -205,3 +207,21 @@ def test_taper_apply2_matches_the_reference_function():
     O.lib().orc_mod_taper_apply2(b, nx, nz, nxb, nzb, np.ascontiguousarray(tx), np.ascontiguousarray(tz))
     assert_bit_equal(b, a, "taper_apply2")
     R._Z13taper_destroyv()
+
+
+def test_image_laplacian_known_answer_bit_exact():
+    """Row f3: the oracle's restatement of laplace.f90 against the committed output of the reference program (built with flang), and,
+    where that binary is present, against a fresh run of it."""
+    import subprocess
+    img = golden_field("dd_3lay_mod_dir_image.f32", (151, 151))
+    want = golden_field("dd_3lay_mod_dir_imalap.f32", (151, 151))
+    got = O.image_laplacian(img, 10.0, 10.0)
+    assert_bit_equal(got, want, "oracle image Laplacian vs laplace.f90's dir.imalap")
+    assert not want[0].any() and not want[-1].any() and not want[:, 0].any() and not want[:, -1].any() and np.abs(want).max() > 1
+    exe = O.ref_lapfilt()
+    if exe is not None:
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            img.tofile(os.path.join(td, "dir.image"))
+            subprocess.check_call([exe], cwd=td)
+            assert_bit_equal(np.fromfile(os.path.join(td, "dir.imalap"), np.float32).reshape(151, 151), want, "fresh run of the reference program")

@@ -74,7 +74,7 @@ def test_deck_reader_details(tmp_path):
 
 
 def test_programs_are_built_and_refuse_bad_usage():
-    for exe in ("stencil_code", "rtm_code", "mod_main", "rtm_main"):
+    for exe in ("stencil_code", "rtm_code", "mod_main", "rtm_main"):   # lapfilt has defaults for everything: no usage error to test
         path = os.path.join(BIN, exe)
         assert os.access(path, os.X_OK), f"{path} missing: run `make -C parallel_finite_difference_computation_amd/csrc`"
         assert subprocess.run([path], capture_output=True).returncode != 0
@@ -348,3 +348,11 @@ def test_rtm_main_program_reproduces_the_reference_image(tmp_path):
     gold = open(os.path.join(GOLDEN, "dd_3lay_mod_dir_image.f32"), "rb").read()
     assert (tmp_path / "dir.image").read_bytes() == gold
     assert (tmp_path / "dir.img").read_bytes() == gold          # one shot: the per-shot image is the stack
+
+
+@pytest.mark.gpu
+def test_lapfilt_program_reproduces_the_reference_output(tmp_path):
+    shutil.copy(os.path.join(GOLDEN, "dd_3lay_mod_dir_image.f32"), tmp_path / "dir.image")
+    r = subprocess.run([os.path.join(BIN, "lapfilt")], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "dir.imalap").read_bytes() == open(os.path.join(GOLDEN, "dd_3lay_mod_dir_imalap.f32"), "rb").read()
