@@ -86,6 +86,7 @@ def run_model_workload(args):
     rec = torch.zeros((nt, n - 2 * NB), device=dev)
     stream = torch.cuda.Stream()
     bufs = [p, pp]
+    torch.cuda.synchronize()           # fills ran on torch's default stream
 
     def run(it0, nsteps):
         ctx.dev_model_steps(bufs[0].data_ptr(), bufs[1].data_ptr(), v2.data_ptr(), srce.data_ptr(), n // 2, n // 2, NB, rec.data_ptr(), it0, nsteps,
@@ -240,6 +241,7 @@ def main():
             roles["ip"], roles["ipp"] = ctx.dev_steps2(ptrs, v2.data_ptr(), srce.data_ptr(), sx, sz, it0, nsteps, it0 > 0,
                                                        roles["ip"], roles["ipp"], stream=stream.cuda_stream)
 
+        torch.cuda.synchronize()       # the fills above ran on torch's default stream; `stream` does not wait for it by itself
         run(0, W)
         stream.synchronize()
         sync_all()
@@ -266,6 +268,7 @@ def main():
                 f_[:, :n] = full_rows[geom.x_off:geom.x_off + geom.nxl].repeat(1, n // 64)
         fields = (a, b) + ((torch.zeros_like(a), torch.zeros_like(a)) if use_pipe else ())
         fw = SlabForward(geom, HipSlabStepper(ctx), fields, v2, srce, sx, sz, overlap=not args.no_overlap, pipe_ctx=ctx if use_pipe else None)
+        torch.cuda.synchronize()       # fields were filled on torch's default stream; the driver's streams do not wait for it
         fw.run(W)
         fw.synchronize()       # also forces torch's lazy creation of both streams outside the timed region
         sync_all()

@@ -120,6 +120,7 @@ class SlabForward:
             self.compute = torch.cuda.Stream()
             self.comm = torch.cuda.Stream()
             self.side = torch.cuda.Stream() if self.pipe_ctx is not None else None   # boundary strips of a split pipeline pass
+            torch.cuda.synchronize()    # whatever filled the fields (another stream) must have landed before these streams touch them
 
     # ---- halo exchange ------------------------------------------------------------------------
     def _exchange_ops(self):

@@ -510,6 +510,7 @@ def test_dev_step4_row_ranges_vs_oracle():
     for ranges in (dict(r0=0, r1=-1), dict(r0=40, r1=97), dict(r0=16, r1=50, r0b=120, r1b=164, xchunk=13), dict(r0=0, r1=33, r0b=150, r1b=180, xchunk=23)):
         out1 = torch.full((nxe, ctx.pitch), 7.0, device=dev)
         out2 = torch.full((nxe, ctx.pitch), -7.0, device=dev)
+        torch.cuda.synchronize()      # the library launches on its own non-blocking stream: torch's fills must have landed
         ctx.dev_step4(newest.data_ptr(), older.data_ptr(), v2.data_ptr(), out1.data_ptr(), out2.data_ptr(), pp_twice=False,
                       d_srce_it=srce.data_ptr(), sx=d["sx"], sz=d["sz"], **ranges)
         ctx.dev_taper_finalize(out1.data_ptr())     # as fdw_forward does for the field it returns as P (the reference downloads the damped d_p, R:285)
@@ -648,3 +649,48 @@ def test_image_laplacian_known_answer_and_oracle():
     assert_bit_equal(F.image_laplacian(rnd, 8.0, 12.5), O.image_laplacian(rnd, 8.0, 12.5), "random image")
     one = np.ones((1, 5), np.float32)
     assert not F.image_laplacian(one, 1.0, 1.0).any()
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_full_size_kernels_agree_and_scale_exactly(n):
+    """BASELINE.json's full-size grids, where the oracle is too slow to be the checker: (a) the three forward kernels (one step, two steps,
+    four steps per pass) agree BITWISE after 9 steps from a noise state with the source on -- the one-step kernel is the one pinned to the
+    oracle at small sizes; (b) linearity: doubling the source doubles the wavefield exactly (a power of two commutes with every rounding)."""
+    import torch
+    dev = torch.device("cuda:0")
+    nb, nt = 64, 16
+    ctx = F.FDWave(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False)
+    pitch = ctx.pitch
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    init = [torch.zeros((n, pitch), device=dev) for _ in range(2)]
+    for t in init:
+        t[:, :n] = 1e-3 * torch.randn((n, n), device=dev, generator=g)
+    v2 = torch.zeros((n, pitch), device=dev)
+    v2[:, :n] = (1500.0 + 2500.0 * torch.rand((n, n), device=dev, generator=g)) ** 2
+    srce_h = O.ricker_wavelet(nt, 0.001, 30.0) + 0.25
+    srce = torch.from_numpy(srce_h.astype(np.float32)).to(dev)
+    srce2 = 2.0 * srce
+
+    def run(mode, s, from_rest, nsteps=9):
+        ctx.set_tuning(two_step=mode)
+        bufs = [torch.zeros((n, pitch), device=dev) for _ in range(4)]
+        if not from_rest:
+            bufs[0].copy_(init[0])
+            bufs[1].copy_(init[1])
+        torch.cuda.synchronize()      # the library launches on its own non-blocking stream: torch's fills must have landed
+        ip, ipp = ctx.dev_steps2([b.data_ptr() for b in bufs], v2.data_ptr(), s.data_ptr(), n // 2 + 3, n // 3, 0, nsteps, False, 0, 1)
+        torch.cuda.synchronize()
+        return bufs[ip], bufs[ipp]
+
+    ctx.set_tuning(two_step=0)
+    assert ctx.steps_per_pass() == 4                     # what bench.py runs at this size
+    ref_p, ref_pp = run(-1, srce, False)
+    for mode in (1, 4):
+        p, pp = run(mode, srce, False)
+        assert torch.equal(pp, ref_pp) and torch.equal(p, ref_p), f"kernel mode {mode} differs from the one-step kernel at {n}^2"
+    assert float(ref_pp.abs().max()) > 0 and bool(torch.isfinite(ref_pp).all())
+    a_p, a_pp = run(4, srce, True)
+    b_p, b_pp = run(4, srce2, True)
+    assert torch.equal(b_pp, 2.0 * a_pp) and torch.equal(b_p, 2.0 * a_p), "doubling the source does not double the field exactly"
+    assert float(a_pp.abs().max()) > 0
