@@ -44,24 +44,13 @@ def synthetic_velocity_rows(n, row0, rows, device):
 
 
 def cpu_baseline(n, seconds_target=12.0):
-    """Oracle's fused loop, one thread, on the same grid size; bounded to ~10-20 s."""
-    from oracle import oracle as O
-    L = O.lib()
-    cx, cz = O.scaled_coefs(ORDER, DX, DX)
-    rng = np.random.default_rng(0)
-    p = (1e-3 * rng.standard_normal((n, n))).astype(np.float32)
-    pp = (1e-3 * rng.standard_normal((n, n))).astype(np.float32)
-    v2 = synthetic_velocity_rows(n, 0, n, "cpu").numpy().astype(np.float32)
-    t0 = time.perf_counter()
-    L.orc_fused_steps(ORDER, n, n, p, pp, v2, cx, cz, DT * DT, 1)
-    one = time.perf_counter() - t0
-    steps = int(max(1, min(40, round(seconds_target / max(one, 1e-3)) - 1)))
-    t0 = time.perf_counter()
-    L.orc_fused_steps(ORDER, n, n, p, pp, v2, cx, cz, DT * DT, steps)
-    dt = time.perf_counter() - t0
-    return {"value": round(n * n * steps / dt / 1e9, 4), "unit": "Gpoints/s", "cores": 1, "kind": "port",
-            "sample": f"{n}x{n} fp32 grid, {steps} fused steps (oracle/fdw_oracle.c orc_fused_steps, gcc -O2 -ffp-contract=off), "
-                      f"single thread, {dt:.1f} s"}
+    """The oracle's fused loop on the same grid size, one thread and all host threads, ~10-20 s per leg, in a process of its own
+    (oracle/cpu_baseline.py) so that torch's thread pool does not compete for the cores."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), str(n), str(seconds_target)], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("cpu_baseline failed: " + r.stderr[-2000:])
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
 
 def run_model_workload(args):

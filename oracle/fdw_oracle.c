@@ -438,6 +438,7 @@ void orc_slab_step(const orc_state *s, int x_off, int nxl, float *p, float *pp, 
     free(lap);
 }
 
+int orc_max_threads(void);
 /* Fused single-pass form of the forward iteration body used ONLY as the cpu_baseline "port" timing
  * kernel in bench.py (same arithmetic per point as lap+time above, full extents, no taper/source):
  * reads p, pp, v2 and writes pp -- the 16 B/point shape the GPU kernel is priced on. */
@@ -447,6 +448,11 @@ void orc_fused_steps(int order, int nxe, int nze, float *p, float *pp, const flo
     int h = order / 2, it, i, j, io;
     for (it = 0; it < nsteps; it++) {
         float *t;
+        /* rows are independent within a step: the OpenMP build (liborc_native.so, oracle/Makefile) shares them out; the arithmetic
+         * per point is unchanged, so the threaded result equals the serial one bit for bit */
+#ifdef _OPENMP
+#pragma omp parallel for private(j, io) schedule(dynamic, 8)
+#endif
         for (i = 0; i < nxe; i++)
             for (j = 0; j < nze; j++) {
                 size_t k = (size_t)i * nze + j;
@@ -465,3 +471,10 @@ void orc_fused_steps(int order, int nxe, int nze, float *p, float *pp, const flo
         t = p; p = pp; pp = t;
     }
 }
+
+#ifdef _OPENMP
+#include <omp.h>
+int orc_max_threads(void) { return omp_get_max_threads(); }
+#else
+int orc_max_threads(void) { return 1; }
+#endif
