@@ -5,11 +5,13 @@
  * [nx][nz]), <tmpdir>/dir.image_lap (zeros, R:477,542), empty dir.snaps / dir.snaps_rec / dir.snapr
  * (R:465-470), ./image.num text dump (R:522-528), and the stdout banners.  The per-shot propagation
  * (fd_forward + fd_back, R:499-518) is one device-resident fdw_shot() call; launch extents are the
- * reference's (compat = 1), so the image equals the reference's.
+ * reference's (compat = 1), so the image equals the reference's.  Shots run side by side on up to FDW_SHOT_WORKERS (default 4) host
+ * threads / streams; models are drawn and images stacked in shot order, so every output is what the serial loop writes.
  * Not reproduced: the `file-teste` debug dump at it == 750 (R:268-281) and the in-loop progress lines. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include <sys/time.h>
 
 #include "fdw_config.h"
@@ -36,6 +38,43 @@ static FILE *open_out(const char *dir, const char *name)
     FILE *f = fopen(path, "w");
     if (!f) fprintf(stderr, "cannot create '%s'\n", path);
     return f;
+}
+
+/* one batch of shots shared out to host threads: worker w takes shots w, w + nw, ... of the batch */
+typedef struct {
+    const fdw_params *prm;
+    int ns, nworkers, is0, nb, nx, nt, sz, gz;
+    const int *sx;
+    const float *srce, *d_obs, *vel2_all;
+    float *imloc_all;
+    size_t ne, ni;
+    volatile int failed;
+} shot_job;
+typedef struct {
+    shot_job *job;
+    int w, nw;
+} shot_worker_arg;
+
+static void *shot_worker(void *p)
+{
+    shot_worker_arg *a = (shot_worker_arg *)p;
+    shot_job *j = a->job;
+    fdw_ctx *ctx = NULL;
+    if (fdw_create(j->prm, 0, &ctx) != FDW_OK) { /* fd_init, R:452 (one context = one stream + its own device buffers per worker) */
+        fprintf(stderr, "fdw_create: %s\n", fdw_last_error());
+        j->failed = 1;
+        return NULL;
+    }
+    for (int b = a->w; b < j->nb && !j->failed; b += a->nw) {
+        const int is = j->is0 + b;
+        if (fdw_shot(ctx, j->vel2_all + (size_t)b * j->ne, j->sx[is], j->sz, j->gz, j->srce, j->d_obs + (size_t)is * j->nx * j->nt,
+                     j->imloc_all + (size_t)b * j->ni, NULL, NULL) != FDW_OK) {
+            fprintf(stderr, "fdw_shot: %s\n", fdw_last_error());
+            j->failed = 1;
+        }
+    }
+    fdw_destroy(ctx);
+    return NULL;
 }
 
 int main(int argc, char **argv)
@@ -101,7 +140,6 @@ int main(int argc, char **argv)
     float *vpe = (float *)calloc(ne, sizeof(float)); /* the reference leaves the border uninitialised (malloc) until extendvel */
     for (int ix = 0; ix < nx; ix++)
         for (int iz = 0; iz < nz; iz++) vpe[(size_t)(ix + nxb) * nze + iz + nzb] = vp[(size_t)ix * nz + iz]; /* R:445-449 */
-    float *vel2 = (float *)malloc(ne * sizeof(float));
 
     fdw_params prm;
     memset(&prm, 0, sizeof prm);
@@ -109,41 +147,73 @@ int main(int argc, char **argv)
     prm.dx = dx; prm.dz = dz; prm.dt = dt; prm.fac = fac;
     prm.compat = 1;   /* the reference's launch extents, R:185-195 */
     prm.coef_cxx = 0; /* libsource.a is C, F:160-192 */
-    fdw_ctx *ctx = NULL;
-    if (fdw_create(&prm, 0, &ctx) != FDW_OK) { /* fd_init, R:452 */
-        fprintf(stderr, "fdw_create: %s\n", fdw_last_error());
-        return EXIT_FAILURE;
-    }
 
-    float *imloc = (float *)malloc(ni * sizeof(float)), *img = (float *)calloc(ni, sizeof(float));
-    float *img_lap = (float *)calloc(ni, sizeof(float));
+    float *img = (float *)calloc(ni, sizeof(float)), *img_lap = (float *)calloc(ni, sizeof(float));
     FILE *fsns = open_out(tmpdir, "dir.snaps"), *fsns2 = open_out(tmpdir, "dir.snaps_rec"), *fsnr = open_out(tmpdir, "dir.snapr");
     FILE *fimg = open_out(tmpdir, "dir.image"), *fimg_lap = open_out(tmpdir, "dir.image_lap"); /* R:464-474 */
     FILE *fnum = fopen("image.num", "w");                                                       /* R:478-479 */
     if (!fimg || !fimg_lap || !fnum) return EXIT_FAILURE;
 
-    for (int is = 0; is < ns; is++) { /* R:480-529 */
-        fprintf(stdout, "** source %d, at (%d,%d) \n", is + 1, sx[is] - nxb, sz - nzb);
-        const float *v = vpe;
-        if (vel_ext_flag)
-            v = vel_ext_rnd + (size_t)is * ne; /* R:484 */
-        else
-            fdw_extendvel_linear(nx, nz, nxb, nzb, vpe); /* R:486: glibc rand(), never seeded */
-        for (size_t k = 0; k < ne; k++) vel2[k] = v[k] * v[k]; /* R:490-494 */
-        memset(imloc, 0, ni * sizeof(float));                  /* R:515 */
-        fprintf(stdout, "\n");
-        fprintf(stdout, "** backward propagation %d, at (%d,%d) \n", is + 1, sx[is] - nxb, sz - nzb);
-        if (fdw_shot(ctx, vel2, sx[is], sz, gz, srce, d_obs + (size_t)is * nx * nt, imloc, NULL, NULL) != FDW_OK) {
-            fprintf(stderr, "fdw_shot: %s\n", fdw_last_error());
-            return EXIT_FAILURE;
+    /* Shots are independent (R:480-529 only couples them through the running image sum), and a shot of a deck this size fills a
+     * few percent of an MI355X: up to FDW_SHOT_WORKERS (default 4) host threads, each with its own context and stream, propagate
+     * shots side by side.  What must stay serial does: the border model draws from ONE rand() stream in shot order (R:486), so all
+     * squared-velocity models are built first, and the images are stacked (and image.num written) in shot order afterwards. */
+    int nworkers = 4;
+    if (getenv("FDW_SHOT_WORKERS")) nworkers = atoi(getenv("FDW_SHOT_WORKERS"));
+    if (nworkers < 1) nworkers = 1;
+    if (nworkers > ns) nworkers = ns;
+    while (nworkers > 1 && (size_t)ns * (ne + ni) * sizeof(float) > ((size_t)8 << 30)) nworkers = 1;   /* big decks: one shot fills the GPU anyway */
+    const int batch = nworkers > 1 ? ns : 1;      /* shots whose model and image are held at once */
+    float *vel2_all = (float *)malloc((size_t)batch * ne * sizeof(float)), *imloc_all = (float *)calloc((size_t)batch * ni, sizeof(float));
+    if (!vel2_all || !imloc_all) {
+        fprintf(stderr, "out of host memory\n");
+        return EXIT_FAILURE;
+    }
+    shot_job job;
+    job.prm = &prm; job.ns = ns; job.nworkers = nworkers; job.sx = sx; job.sz = sz; job.gz = gz; job.srce = srce; job.d_obs = d_obs;
+    job.nx = nx; job.nt = nt; job.ne = ne; job.ni = ni; job.vel2_all = vel2_all; job.imloc_all = imloc_all; job.failed = 0;
+
+    for (int is0 = 0; is0 < ns; is0 += batch) {
+        const int nb = is0 + batch <= ns ? batch : ns - is0;
+        for (int b = 0; b < nb; b++) {               /* models in shot order: the rand() stream is sequential */
+            const int is = is0 + b;
+            const float *v = vpe;
+            if (vel_ext_flag)
+                v = vel_ext_rnd + (size_t)is * ne; /* R:484 */
+            else
+                fdw_extendvel_linear(nx, nz, nxb, nzb, vpe); /* R:486: glibc rand(), never seeded */
+            float *v2 = vel2_all + (size_t)b * ne;
+            for (size_t k = 0; k < ne; k++) v2[k] = v[k] * v[k]; /* R:490-494 */
         }
-        fprintf(stdout, "\n");
-        fprintf(fnum, "======== %i ========\n", is); /* R:522-528: iz outer, ix inner, running sum */
-        for (int iz = 0; iz < nz; iz++)
-            for (int ix = 0; ix < nx; ix++) {
-                img[(size_t)ix * nz + iz] += imloc[(size_t)ix * nz + iz];
-                fprintf(fnum, " %f \n", img[(size_t)ix * nz + iz]);
+        job.is0 = is0; job.nb = nb;
+        memset(imloc_all, 0, (size_t)nb * ni * sizeof(float));                                 /* R:515 */
+        const int nw = nb < nworkers ? nb : nworkers;
+        pthread_t th[64];
+        shot_worker_arg wa[64];
+        for (int w = 0; w < nw; w++) {
+            wa[w].job = &job; wa[w].w = w; wa[w].nw = nw;
+            if (w > 0 && pthread_create(&th[w], NULL, shot_worker, &wa[w]) != 0) {
+                fprintf(stderr, "pthread_create failed\n");
+                return EXIT_FAILURE;
             }
+        }
+        shot_worker(&wa[0]);
+        for (int w = 1; w < nw; w++) pthread_join(th[w], NULL);
+        if (job.failed) return EXIT_FAILURE;
+        for (int b = 0; b < nb; b++) {               /* R:480-529 in shot order */
+            const int is = is0 + b;
+            const float *imloc = imloc_all + (size_t)b * ni;
+            fprintf(stdout, "** source %d, at (%d,%d) \n", is + 1, sx[is] - nxb, sz - nzb);
+            fprintf(stdout, "\n");
+            fprintf(stdout, "** backward propagation %d, at (%d,%d) \n", is + 1, sx[is] - nxb, sz - nzb);
+            fprintf(stdout, "\n");
+            fprintf(fnum, "======== %i ========\n", is); /* R:522-528: iz outer, ix inner, running sum */
+            for (int iz = 0; iz < nz; iz++)
+                for (int ix = 0; ix < nx; ix++) {
+                    img[(size_t)ix * nz + iz] += imloc[(size_t)ix * nz + iz];
+                    fprintf(fnum, " %f \n", img[(size_t)ix * nz + iz]);
+                }
+        }
     }
     gettimeofday(&end, NULL);
     /* the reference divides integers (whole seconds, R:536); we print the real value */
@@ -158,9 +228,8 @@ int main(int argc, char **argv)
     fclose(fimg);
     fclose(fimg_lap);
     fclose(fnum);
-    fdw_destroy(ctx);
-    free(srce); free(sx); free(vel_ext_rnd); free(d_obs); free(vp); free(vpe); free(vel2);
-    free(imloc); free(img); free(img_lap);
+    free(srce); free(sx); free(vel_ext_rnd); free(d_obs); free(vp); free(vpe); free(vel2_all);
+    free(imloc_all); free(img); free(img_lap);
     fdw_deck_free(deck);
     return 0;
 }
