@@ -694,3 +694,43 @@ def test_full_size_kernels_agree_and_scale_exactly(n):
     b_p, b_pp = run(4, srce2, True)
     assert torch.equal(b_pp, 2.0 * a_pp) and torch.equal(b_p, 2.0 * a_p), "doubling the source does not double the field exactly"
     assert float(a_pp.abs().max()) > 0
+
+
+def test_large_ragged_compat_grid_kernels_agree():
+    """A large grid with awkward extents (3001 x 4099, reference launch truncation on: the last row and three columns are never time-stepped,
+    the row pitch is padded) where the library picks the wave pipeline by itself: bitwise the one-step kernel's result, static rows included."""
+    import torch
+    dev = torch.device("cuda:0")
+    nxe, nze, nb, nt = 3001, 4099, 40, 16
+    ctx = F.FDWave(8, nxe, nze, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=True)
+    xlim, zlim, ztap = ctx.extents()
+    assert (xlim, zlim) == (3000, 4096) and ctx.steps_per_pass() == 4
+    pitch = ctx.pitch
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    init = [torch.zeros((nxe, pitch), device=dev) for _ in range(2)]
+    for t in init:
+        t[:, :nze] = 1e-3 * torch.randn((nxe, nze), device=dev, generator=g)
+        t[xlim:, :ztap] = 0            # precondition of the lazy damping: rows the reference never time-steps are zero inside the damped strip
+    v2 = torch.zeros((nxe, pitch), device=dev)
+    v2[:, :nze] = (1500.0 + 2500.0 * torch.rand((nxe, nze), device=dev, generator=g)) ** 2
+    srce = torch.from_numpy((O.ricker_wavelet(nt, 0.001, 30.0) + 0.25).astype(np.float32)).to(dev)
+
+    def run(mode, nsteps):
+        ctx.set_tuning(two_step=mode)
+        bufs = [torch.full((nxe, pitch), 3.0, device=dev) for _ in range(4)]
+        for b in bufs:
+            b[:, nze:] = 0
+        bufs[0].copy_(init[0])
+        bufs[1].copy_(init[1])
+        torch.cuda.synchronize()
+        ip, ipp = ctx.dev_steps2([b.data_ptr() for b in bufs], v2.data_ptr(), srce.data_ptr(), nxe // 2, nze // 3, 0, nsteps, False, 0, 1)
+        torch.cuda.synchronize()
+        return bufs[ip], bufs[ipp]
+
+    for nsteps in (8, 11):
+        ref_p, ref_pp = run(-1, nsteps)
+        for mode in (0, 1):
+            p, pp = run(mode, nsteps)
+            assert torch.equal(pp, ref_pp) and torch.equal(p, ref_p), f"mode {mode}, {nsteps} steps"
+        assert float(ref_pp.abs().max()) > 0 and bool(torch.isfinite(ref_pp).all())
