@@ -329,7 +329,7 @@ def main():
             steps_per_launch = ctx.steps_per_pass()          # 4: wave pipeline, 2: two-step kernel, 1: one-step kernel
             rem = K % steps_per_launch
             launches = K // steps_per_launch + (rem // 2 + rem % 2 if ctx.two_step_active() else rem)
-            kname = {4: "fdw::fdw_stepn_kernel<4,4,true,1,2> (four time steps per launch: one wave per time level, rows handed through LDS)",
+            kname = {4: "fdw::fdw_stepn_kernel<4,4,true,1,2,false> (four time steps per launch: one wave per time level, rows handed through LDS)",
                      2: "fdw::fdw_step2_kernel<4,true,1,false,2> (two time steps per launch)", 1: "fdw::fdw_step_kernel<4,true,1,false,false,2>"}[steps_per_launch]
             launch_ms = dev_ms / launches
             algo = ALGO_BYTES_PER_POINT * pts_per_launch * steps_per_launch      # 16 B/point/step x steps in one launch
