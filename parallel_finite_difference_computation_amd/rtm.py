@@ -87,19 +87,33 @@ def run(deck_path, out=sys.stdout):
     vel_ext = np.memmap(d["vel_ext_file"], np.float32, "r", shape=(ns, nxe, nze)) if d["vel_ext_file"] else None
     vpe = np.zeros((nxe, nze), np.float32)
     vpe[nxb:nxb + nx, nzb:nzb + nz] = vp
-    ctx = api.FDWave(d["order"], nxe, nze, nxb, nzb, nt, d["fac"], d["dx"], d["dz"], d["dt"], compat=True, device=local)
-    mine = {}
-    for s in range(ns):
-        if vel_ext is not None:
-            v = np.asarray(vel_ext[s])
-        else:
-            api.extendvel_linear(vpe, nx, nz, nxb, nzb)        # every rank replays the whole rand() stream (fd-code.cu:486)
-            v = vpe
-        if s % world != rank:
-            continue
-        print(f"** source {s + 1}, at ({sx[s] - nxb},{sz - nzb}) " + (f" [rank {rank}]" if world > 1 else ""), file=out, flush=True)
-        v2 = (v * v).astype(np.float32)
-        mine[s] = ctx.shot(v2, sx[s], sz, gz, srce, np.ascontiguousarray(d_obs[s]))
+    # a shot of a small deck fills a few percent of one GPU: this rank's shots go through up to FDW_SHOT_WORKERS (default 2) contexts
+    # (own stream and buffers each) on host threads; ctypes releases the GIL inside the library
+    import concurrent.futures
+    import threading
+    nworkers = max(1, int(os.environ.get("FDW_SHOT_WORKERS", "2")))
+    local_ctx = threading.local()
+
+    def one_shot(s, v2):
+        if not hasattr(local_ctx, "ctx"):
+            local_ctx.ctx = api.FDWave(d["order"], nxe, nze, nxb, nzb, nt, d["fac"], d["dx"], d["dz"], d["dt"], compat=True, device=local)
+        return s, local_ctx.ctx.shot(v2, sx[s], sz, gz, srce, np.ascontiguousarray(d_obs[s]))
+
+    mine, pending = {}, []
+    with concurrent.futures.ThreadPoolExecutor(max_workers=nworkers) as pool:
+        for s in range(ns):
+            if vel_ext is not None:
+                v = np.asarray(vel_ext[s])
+            else:
+                api.extendvel_linear(vpe, nx, nz, nxb, nzb)        # every rank replays the whole rand() stream (fd-code.cu:486)
+                v = vpe
+            if s % world != rank:
+                continue
+            print(f"** source {s + 1}, at ({sx[s] - nxb},{sz - nzb}) " + (f" [rank {rank}]" if world > 1 else ""), file=out, flush=True)
+            pending.append(pool.submit(one_shot, s, (v * v).astype(np.float32)))
+        for f in pending:
+            s, im = f.result()
+            mine[s] = im
     # stack in shot order on rank 0 (fd-code.cu:522-528)
     if world > 1:
         gathered = [None] * world
