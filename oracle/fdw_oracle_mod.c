@@ -33,17 +33,24 @@ void orc_mod_taper_tables(int nxb, int nzb, float F, float *taperx, float *taper
     for (int i = 0; i < nzb; i++) taperz[i] = exp(-pow((double)(F * (nzb - i)), 2));
 }
 
-/* T:7-23: replicate the edge values of the (squared) velocity outwards */
+/* T:7-23: replicate the edge values of the (squared) velocity outwards: first along z for the interior rows (top from the first
+ * interior sample, bottom from the last), then whole rows along x (left rows from the first interior row, right rows from the last) */
 void orc_mod_extendvel(int nx, int nz, int nxb, int nzb, float *vel)
 {
-    const int rnz = nz + 2 * nzb;
-    for (int ix = 0; ix < nx; ix++) {
-        for (int iz = 0; iz < nzb; iz++) vel[(ix + nxb) * rnz + iz] = vel[(ix + nxb) * rnz + nzb];
-        for (int iz = nzb + nz; iz < nz + 2 * nzb; iz++) vel[(ix + nxb) * rnz + iz] = vel[(ix + nxb) * rnz + nz + nzb - 1];
+    const size_t nze = (size_t)nz + 2 * (size_t)nzb;
+    const int nxe = nx + 2 * nxb;
+    for (int row = nxb; row < nxb + nx; row++) {
+        float *r = vel + (size_t)row * nze;
+        const float top = r[nzb], bottom = r[nzb + nz - 1];
+        for (int k = 0; k < nzb; k++) {
+            r[k] = top;
+            r[nzb + nz + k] = bottom;
+        }
     }
-    for (int iz = 0; iz < nz + 2 * nzb; iz++) {
-        for (int ix = 0; ix < nxb; ix++) vel[ix * rnz + iz] = vel[nxb * rnz + iz];
-        for (int ix = nxb + nx; ix < nx + 2 * nxb; ix++) vel[ix * rnz + iz] = vel[(nx + nxb - 1) * rnz + iz];
+    const float *first = vel + (size_t)nxb * nze, *last = vel + (size_t)(nxb + nx - 1) * nze;
+    for (int row = 0; row < nxe; row++) {
+        if (row >= nxb && row < nxb + nx) continue;
+        memcpy(vel + (size_t)row * nze, row < nxb ? first : last, nze * sizeof(float));
     }
 }
 
@@ -62,18 +69,26 @@ void orc_mod_ricker_wavelet(int nt, float dt, float peak, float *s)
     }
 }
 
-/* T:46-66 taper_apply: z factors on the top and bottom strips of every row, then x factors on the left and right strips of
- * every column */
+/* T:46-66 taper_apply: every sample of the four strips is multiplied by its z factor first (top strip taperz[iz], bottom strip
+ * mirrored) and then, in the left / right strips, by its x factor (mirrored on the right); an element-wise operation, so only the
+ * order of the two products per sample matters */
+static float mod_strip_factor(const float *taper, int nb, int n, int i)
+{
+    if (i < nb) return taper[i];
+    if (i >= n - nb) return taper[n - 1 - i];
+    return 1.0f;
+}
 void orc_mod_taper_apply(float *pp, int nx, int nz, int nxb, int nzb, const float *taperx, const float *taperz)
 {
-    const int nze = nz + 2 * nzb;
-    for (int itx = 0; itx < nx + 2 * nxb; itx++) {
-        for (int itz = 0; itz < nzb; itz++) pp[itx * nze + itz] *= taperz[itz];
-        for (int itz = nzb - 1, i = 0; itz > -1; itz--, i++) pp[itx * nze + nz + nzb + i] *= taperz[itz];
-    }
-    for (int itz = 0; itz < nz + 2 * nzb; itz++) {
-        for (int itx = 0; itx < nxb; itx++) pp[itx * nze + itz] *= taperx[itx];
-        for (int itx = nxb - 1, i = 0; itx > -1; itx--, i++) pp[(nx + nxb + i) * nze + itz] *= taperx[itx];
+    const int nxe = nx + 2 * nxb, nze = nz + 2 * nzb;
+    for (int ix = 0; ix < nxe; ix++) {
+        const int xstrip = ix < nxb || ix >= nxe - nxb;
+        const float fx = mod_strip_factor(taperx, nxb, nxe, ix);
+        float *row = pp + (size_t)ix * nze;
+        for (int iz = 0; iz < nze; iz++) {
+            if (iz < nzb || iz >= nze - nzb) row[iz] *= mod_strip_factor(taperz, nzb, nze, iz);
+            if (xstrip) row[iz] *= fx;
+        }
     }
 }
 
@@ -100,15 +115,20 @@ void orc_mod_fd_step(int order, const float *coefs, float dx2inv, float dz2inv, 
         }
 }
 
-/* PS:12-58 ptsrc: 7x7 Gaussian blob; exp(float) is the float overload under g++, the product and the sum are float */
+/* PS:12-58 ptsrc: a Gaussian blob of radius 3 cells around (xs, zs), clipped by the array; exp(float) is the float overload under
+ * g++, the product and the sum are float */
 void orc_mod_ptsrc(int xs, int zs, int nx, int nz, float ts, float *s)
 {
-    const float xsn = xs, zsn = zs;
-    for (int ix = (xs - 3 > 0 ? xs - 3 : 0); ix <= (xs + 3 < nx - 1 ? xs + 3 : nx - 1); ++ix)
-        for (int iz = (zs - 3 > 0 ? zs - 3 : 0); iz <= (zs + 3 < nz - 1 ? zs + 3 : nz - 1); ++iz) {
-            const float xn = ix - xsn, zn = iz - zsn;
-            s[ix * nz + iz] += ts * expf(-xn * xn - zn * zn);
+    for (int dx = -3; dx <= 3; dx++) {
+        const int ix = xs + dx;
+        if (ix < 0 || ix > nx - 1) continue;
+        for (int dz = -3; dz <= 3; dz++) {
+            const int iz = zs + dz;
+            if (iz < 0 || iz > nz - 1) continue;
+            const float xn = (float)ix - (float)xs, zn = (float)iz - (float)zs;
+            s[(size_t)ix * nz + iz] += ts * expf(-xn * xn - zn * zn);
         }
+    }
 }
 
 /* M:140-174: one shot of the modelling loop.  v2 is the extended squared velocity, data is [nx][nt]. */
@@ -141,17 +161,19 @@ void orc_mod_shot(int order, int nx, int nz, int nxb, int nzb, int nt, float dx,
  * Pin: orc_rtm_stored_shot reproduces build/3lay_mod/dir.image bit-exactly from that deck, model and dobs.bin.
  * ====================================================================================================================== */
 
-/* T:68-83 taper_apply2 */
+/* T:68-83 taper_apply2: only the top strip is damped -- z factor for every row, then the x factor in the left / right rows */
 void orc_mod_taper_apply2(float *pp, int nx, int nz, int nxb, int nzb, const float *taperx, const float *taperz)
 {
-    const int nze = nz + 2 * nzb;
-    for (int itx = 0; itx < nx + 2 * nxb; itx++)
-        for (int itz = 0; itz < nzb; itz++) pp[itx * nze + itz] *= taperz[itz];
-    for (int itx = 0, itxr = nx + 2 * nxb - 1; itx < nxb; itx++, itxr--)
-        for (int itz = 0; itz < nzb; itz++) {
-            pp[itx * nze + itz] *= taperx[itx];
-            pp[itxr * nze + itz] *= taperx[itx];
+    const int nxe = nx + 2 * nxb, nze = nz + 2 * nzb;
+    for (int ix = 0; ix < nxe; ix++) {
+        const int xstrip = ix < nxb || ix >= nxe - nxb;
+        const float fx = mod_strip_factor(taperx, nxb, nxe, ix);
+        float *row = pp + (size_t)ix * nze;
+        for (int iz = 0; iz < nzb; iz++) {
+            row[iz] *= taperz[iz];
+            if (xstrip) row[iz] *= fx;
         }
+    }
 }
 
 /* RM:158-240 for one shot.  dobs_flat is the WHOLE gather file [ns][nx][nt] (n_flat floats) and `is` the shot: the reference reads
