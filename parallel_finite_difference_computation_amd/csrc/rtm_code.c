@@ -215,6 +215,12 @@ int main(int argc, char **argv)
                 }
         }
     }
+    /* opt-in extension (deck key image_lap=1): fill dir.image_lap with the reference's own offline filter (models/3lay_mod/laplace.f90)
+     * of the stacked image instead of the zeros the reference writes (R:477, R:542) */
+    if (fdw_deck_int(deck, "image_lap") == 1 && fdw_image_laplacian(0, img, nx, nz, dx, dz, img_lap) != FDW_OK) {
+        fprintf(stderr, "fdw_image_laplacian: %s\n", fdw_last_error());
+        return EXIT_FAILURE;
+    }
     gettimeofday(&end, NULL);
     /* the reference divides integers (whole seconds, R:536); we print the real value */
     const double exec = ((end.tv_sec - start.tv_sec) * 1000000.0 + (end.tv_usec - start.tv_usec)) / 1000000.0;

@@ -147,6 +147,13 @@ def test_rtm_code_program_vs_oracle_pipeline(tmp_path, with_vel_ext):
     assert np.abs(got).max() > 0
     lap = np.fromfile(tmp_path / "output" / "dir.image_lap", np.float32)
     assert lap.size == nx * nz and not lap.any()
+    if with_vel_ext:      # opt-in deck key: dir.image_lap = the reference's offline Laplacian filter of the stacked image
+        (tmp_path / "input.dat").write_text((tmp_path / "input.dat").read_text() + "image_lap=1\n")
+        r2 = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=tmp_path, capture_output=True, text=True)
+        assert r2.returncode == 0, r2.stderr
+        lap = np.fromfile(tmp_path / "output" / "dir.image_lap", np.float32).reshape(nx, nz)
+        assert_bit_equal(lap, O.image_laplacian(img, 10.0, 10.0), "dir.image_lap with image_lap=1")
+        assert_bit_equal(np.fromfile(tmp_path / "output" / "dir.image", np.float32).reshape(nx, nz), img, "dir.image unchanged")
     for name in ("dir.snaps", "dir.snaps_rec", "dir.snapr"):
         assert os.path.getsize(tmp_path / "output" / name) == 0
     lines = (tmp_path / "image.num").read_text().splitlines()
