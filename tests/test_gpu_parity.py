@@ -651,7 +651,7 @@ def test_image_laplacian_known_answer_and_oracle():
     assert not F.image_laplacian(one, 1.0, 1.0).any()
 
 
-@pytest.mark.parametrize("n", [4096, 8192])
+@pytest.mark.parametrize("n", [4096, 8192, 16384])
 def test_full_size_kernels_agree_and_scale_exactly(n):
     """BASELINE.json's full-size grids, where the oracle is too slow to be the checker: (a) the three forward kernels (one step, two steps,
     four steps per pass) agree BITWISE after 9 steps from a noise state with the source on -- the one-step kernel is the one pinned to the
