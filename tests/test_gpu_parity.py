@@ -734,3 +734,102 @@ def test_large_ragged_compat_grid_kernels_agree():
             p, pp = run(mode, nsteps)
             assert torch.equal(pp, ref_pp) and torch.equal(p, ref_p), f"mode {mode}, {nsteps} steps"
         assert float(ref_pp.abs().max()) > 0 and bool(torch.isfinite(ref_pp).all())
+
+
+@pytest.mark.parametrize("world,ksteps,pipe", [(3, 8, True), (2, 4, True), (3, 4, False)], ids=["3slabs-pipeline-k8", "2slabs-pipeline-k4", "3slabs-onestep-k4"])
+def test_slabforward_with_asynchronous_streams_on_one_gpu(world, ksteps, pipe):
+    """The stream choreography of decomp.SlabForward under REAL asynchrony (what RCCL gives and gloo does not): every slab keeps its own
+    compute / comm / side streams, the cycle generators are advanced in lockstep on the host, and a halo transfer is a device-to-device copy
+    enqueued on the RECEIVER's comm stream that waits (by event) for the SENDER's comm stream, which in turn waited for the sender's compute
+    or side stream exactly as SlabForward.exchange() does; the sender's comm stream is held until the copy is done, like a send in flight.
+    Nothing is synchronised with the host until the end.  Bitwise equal to a single-domain run of the one-step kernel."""
+    import torch
+    from parallel_finite_difference_computation_amd.decomp import HipSlabStepper, SlabForward, SlabGeometry
+    dev = torch.device("cuda:0")
+    nxe, nze, nb, nt = 1500, 2100, 40, 64
+    nsteps = 3 * ksteps + 3                                    # full cycles (overlapped exchanges) + leftover steps
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(5)
+    full = [1e-3 * torch.randn((nxe, nze), device=dev, generator=g0) for _ in range(2)]
+    v2f = (1500.0 + 2500.0 * torch.rand((nxe, nze), device=dev, generator=g0)) ** 2
+    srce = torch.from_numpy((O.ricker_wavelet(nt, 0.001, 30.0) + 0.25).astype(np.float32)).to(dev)
+    sx, sz = nxe // 2 + 1, nze // 3
+    mkctx = lambda **kw: F.FDWave(8, nxe, nze, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False, **kw)
+    # single-domain reference (one-step kernel)
+    ref = mkctx()
+    ref.set_tuning(two_step=-1)
+    rb = [torch.zeros((nxe, ref.pitch), device=dev) for _ in range(4)]
+    rb[0][:, :nze], rb[1][:, :nze] = full[0], full[1]
+    rv2 = torch.zeros((nxe, ref.pitch), device=dev)
+    rv2[:, :nze] = v2f
+    torch.cuda.synchronize()
+    ip, ipp = ref.dev_steps2([b.data_ptr() for b in rb], rv2.data_ptr(), srce.data_ptr(), sx, sz, 0, nsteps, False, 0, 1)
+    torch.cuda.synchronize()
+    fws = []
+    for r in range(world):
+        g = SlabGeometry(r, world, nxe, 4, ksteps)
+        ctx = mkctx(slab=(g.x_off, g.nxl))
+        if pipe:
+            ctx.set_tuning(two_step=4)
+        rows = slice(g.x_off, g.x_off + g.nxl)
+        fields = [torch.zeros((g.nxl, ctx.pitch), device=dev) for _ in range(4 if pipe else 2)]
+        fields[0][:, :nze], fields[1][:, :nze] = full[0][rows], full[1][rows]
+        if g.has_lo:                                              # ghosts start stale: the first exchange must bring them
+            fields[0][:g.g_lo] = 9.0
+            fields[1][:g.g_lo] = -9.0
+        v2 = torch.zeros((g.nxl, ctx.pitch), device=dev)
+        v2[:, :nze] = v2f[rows]
+        fw = SlabForward(g, HipSlabStepper(ctx), fields, v2, srce, sx, sz, overlap=True, pipe_ctx=ctx if pipe else None)
+        assert (fw.pipe_ctx is not None) == pipe
+        fw.g.world = world
+        fws.append(fw)
+    torch.cuda.synchronize()
+
+    def exchange_all():
+        ready = []
+        for fw in fws:                                            # sender side of SlabForward.exchange(): comm waits for compute / side
+            fw.comm.wait_stream(fw._send_after if fw._send_after is not None else fw.compute)
+            fw._send_after = None
+            ev = torch.cuda.Event()
+            ev.record(fw.comm)
+            ready.append(ev)
+        done = []
+        for r, fw in enumerate(fws):
+            g = fw.g
+            with torch.cuda.stream(fw.comm):
+                for nb_r, recv, send in ((r - 1, g.recv_lo(), "send_hi"), (r + 1, g.recv_hi(), "send_lo")):
+                    if 0 <= nb_r < world and ((nb_r < r and g.has_lo) or (nb_r > r and g.has_hi)):
+                        fw.comm.wait_event(ready[nb_r])
+                        s0, s1 = getattr(fws[nb_r].g, send)()
+                        for mine, theirs in ((fw.d_p, fws[nb_r].d_p), (fw.d_pp, fws[nb_r].d_pp)):
+                            mine[recv[0]:recv[1]].copy_(theirs[s0:s1], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(fw.comm)
+                        done.append((nb_r, ev))
+        for nb_r, ev in done:                                     # a send is in flight until its data has been taken
+            fws[nb_r].comm.wait_event(ev)
+        for fw in fws:
+            fw.fresh = True
+
+    done_steps = 0
+    while done_steps < nsteps:
+        kk = min(ksteps, nsteps - done_steps)
+        gens = [fw.cycle(kk, done_steps + kk < nsteps, fw.compute.cuda_stream) for fw in fws]
+        while True:
+            tags = [next(gn, None) for gn in gens]
+            assert len(set(tags)) == 1, tags
+            if tags[0] is None:
+                break
+            if tags[0] == "pre":                                  # SlabForward.run()'s handling of the two yield points
+                if not fws[0].fresh:
+                    exchange_all()
+                for fw in fws:
+                    fw.compute.wait_stream(fw.comm)
+                    fw.fresh = False
+            else:
+                exchange_all()
+        done_steps += kk
+    torch.cuda.synchronize()
+    own = lambda fw, f: fw.owned(f)[:, :nze]
+    assert torch.equal(torch.cat([own(fw, fw.d_pp) for fw in fws]), rb[ipp][:, :nze]), "newest field differs from the single-domain run"
+    assert torch.equal(torch.cat([own(fw, fw.d_p) for fw in fws]), rb[ip][:, :nze]), "older field differs from the single-domain run"
