@@ -118,7 +118,7 @@ int fdw_shot(fdw_ctx *ctx, const float *v2, int sx, int sz, int gz, const float 
  *                   mode 2 RECV  taper + Laplacian + leap-frog + receivers + imaging (R:325-329)
  *                 d_p is read, d_pp is read and overwritten with the new field (the caller swaps
  *                 roles afterwards, R:260-262).  pp_twice: 0 on the first step after fresh data,
- *                 1 afterwards (see fdw_kernels.hip "lazy taper").  d_inj: FWD: device pointer to
+ *                 1 afterwards (see csrc/fdw_device.h "lazy taper").  d_inj: FWD: device pointer to
  *                 the source sample of this step, inj_x/inj_z its GLOBAL position (inj_x < 0: no
  *                 source); RECV: device pointer to nx receiver samples of this step (row-contiguous,
  *                 i.e. d_obs transposed to [it][ix]), inj_z = gz.  d_psrc/d_img: RECV only.

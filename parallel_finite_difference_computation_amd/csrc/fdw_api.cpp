@@ -300,7 +300,7 @@ extern "C" void fdw_destroy(fdw_ctx* c)
 // ------------------------------------------------------------------------------------------------
 // launch geometry + one step
 // ------------------------------------------------------------------------------------------------
-// ring size of the register-ring kernel for (half order, prefetch) -- must match RingGeom in fdw_kernels.hip
+// ring size of the register-ring kernel for (half order, prefetch) -- must match RingGeom in fdw_device.h
 static int ring_rows(int h, int pf) { return ((2 * h + pf + pf - 1) / pf) * pf; }
 static int effective_prefetch(const fdw_ctx* c) { return (c->h == 4 && c->prefetch >= 1 && c->prefetch <= 3) ? c->prefetch : 2; }
 

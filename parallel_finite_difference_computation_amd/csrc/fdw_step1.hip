@@ -1,0 +1,481 @@
+// fdw_step1.hip -- one time step per pass: the fused register-ring kernel (all modes and dialects), the generic-order kernel, the
+// small utility kernels and their launchers.  Design notes: fdw_device.h.
+#include "fdw_device.h"
+
+#pragma clang fp contract(off)
+
+namespace fdw {
+
+// ------------------------------------------------------------------------------------------------
+// fused step kernel
+//   H       half order (1..4)
+//   TAPER   apply the lazy top-strip damping to p / pp
+//   INJ     0 none, 1 point source (kernel_src), 2 receiver row (kernel_sism), 3 7x7 Gaussian point source (ptsrc.c of the CPU-serial sibling)
+//   IMG     img += psrc * pp_new epilogue (kernel_img)
+//   LAPONLY store the Laplacian itself into a.pp (stencil_code path, S:110-135); no update
+//   DD      arithmetic of the CPU-serial sibling's fd_step (single accumulator, per-term scaling) + one trace sample per row
+//   PF      software prefetch distance in rows
+// block = 256 threads = 4 independent waves (no LDS, no barrier).
+//
+// ONE code path for every tile.  Every global load of the march is unconditional (addresses are
+// clamped into the slab instead of being predicated), so the compiler's s_waitcnt bookkeeping stays
+// exact and the look-ahead loads really stay in flight.  Whatever a clamped load brings in only ever
+// reaches outputs that the column / row masks zero: rows outside the slab are taps of rows whose
+// Laplacian is masked (lap_x0 >= H, lap_x1 <= nxl-H), columns outside the grid are taps of columns
+// >= nze-H.  Edge handling (masks, damping, injection) is wave-uniform branches around VALU / scalar
+// loads only.
+// ------------------------------------------------------------------------------------------------
+template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false>
+__device__ __forceinline__ void march(const StepArgs& a, const int lane, const int zs, const int xa, const int xe)
+{
+    using G = RingGeom<H, PF>;
+    constexpr int R = G::R, LOOK = G::LOOK;
+#if FDW_ABL_BITS & 32
+    const size_t pitch = 0;   // every row aliases row 0: loads become L1 hits -> pure issue/VALU time
+#else
+    const size_t pitch = (size_t)a.pitch;
+#endif
+    const int z0 = zs + lane * 4;
+    const bool partial = (zs + 256 > a.pitch);              // wave-uniform: last strip of a ragged row
+    const bool act = z0 < a.pitch;                          // pitch % 4 == 0: a float4 never straddles a row end
+    const unsigned voff = (unsigned)min(z0, a.pitch - 4) * 4u;
+    // strip halo in ONE load by all lanes: lane 0 fetches the 4 columns left of the strip, every other
+    // lane the 4 columns right of it (a single 16-B piece; only lane 63 consumes it).
+    const unsigned hoff = (unsigned)((lane == 0) ? max(zs - 4, 0) : min(zs + 256, a.pitch - 4)) * 4u;
+    const bool lane_first = (lane == 0), lane_last = (lane == 63);
+    const int rowmax = min(a.nxl, xe + H) - 1;              // last row of p this wave can need
+
+    // wave-uniform classification of the tile
+    const bool zedge = (zs < a.lap_z0) || (zs + 256 > a.lap_z1) || (!LAPONLY && zs + 256 > a.upd_z1);
+    const bool xedge = (xa < a.lap_x0) || (xe > a.lap_x1);
+    const bool wave_tap = TAPER && (zs - 4 < a.ztap);
+    const bool xtap = wave_tap && ((xa - H < a.xt_lo) || (xe + H > a.xt_hi));   // rows with an x factor / no z factor
+    bool inj_here = false;
+    if (INJ == 1) inj_here = (a.inj_x >= xa) && (a.inj_x < xe) && (a.inj_z >= zs) && (a.inj_z < zs + 256);
+    if (INJ == 2) inj_here = (a.inj_z >= zs) && (a.inj_z < zs + 256) && (a.inj_x < xe) && (a.inj_x + a.inj_n > xa);
+    if (INJ == 3) inj_here = (a.inj_z + 3 >= zs) && (a.inj_z - 3 < zs + 256) && (a.inj_x + 3 >= xa) && (a.inj_x - 3 < xe);   // 7x7 blob
+    const float inj_src = ((INJ == 1 || INJ == 3) && inj_here) ? sload(a.inj, 0) : 0.0f;
+    const bool rec_here = DD && (a.rec != nullptr) && (a.rec_z >= zs) && (a.rec_z < zs + 256);
+    const CoefPairs<H> cpk = coef_pairs<H>(a.cx, a.cz);
+
+    // per-lane column masks and damping factors
+    bool mlap[4], mupd[4], znc[4], znh[4], ihit[4];
+    float tzc[4], tzh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int z = z0 + e;
+        mlap[e] = (z >= a.lap_z0) && (z < a.lap_z1);
+        mupd[e] = z < a.upd_z1;
+        ihit[e] = (z == a.inj_z);
+        znc[e] = znh[e] = false;
+        tzc[e] = tzh[e] = 1.0f;
+    }
+    if (wave_tap) {
+        const int hz = (lane == 0) ? zs - 4 : zs + 256;     // true (unclamped) column of this lane's halo piece
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int zc = z0 + e, zh = hz + e;
+            znc[e] = zc < a.ztap;
+            znh[e] = (zh >= 0) && (zh < a.ztap);
+            if (znc[e]) tzc[e] = a.taperz[zc];
+            if (znh[e]) tzh[e] = a.taperz[zh];
+        }
+    }
+    // one application of the reference's damping to a row held in registers (R:103-114)
+    auto taper_row = [&](f4& v, const float* tz, const bool* zone, int row) {
+        if (!xtap) {   // common case: no x factor on these rows, every row gets the z factor; *1.0f is exact
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = v.v[e] * tz[e];
+        } else {
+            const int rc = min(max(row, 0), a.nxl - 1);
+            const float txr = sload(a.txfac, rc);
+            const bool rowtz = row < a.tz_x1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = taper1(v.v[e], tz[e], zone[e], rowtz, txr);
+        }
+    };
+
+    // ---- loaders: unconditional, clamped --------------------------------------------------------
+    auto load_p = [&](int row) -> f4 { return f4_load(a.p + (size_t)min(max(row, 0), rowmax) * pitch, voff); };
+    auto load_halo = [&](int row) -> f4 {
+#if FDW_ABL_BITS & 2
+        return f4_zero();
+#endif
+        return f4_load(a.p + (size_t)row * pitch, hoff);
+    };
+    auto load_plain = [&](const float* base, int row) -> f4 { return f4_load_stream(base + (size_t)row * pitch, voff); };
+
+    // ---- prologue: ring rows xa-H .. xa-H+R-1; pointwise rows xa .. xa+PF-1 --------------------
+    // Issue order matters: the loop-header s_waitcnt is the stricter of (prologue state, end-of-turn
+    // state).  Issuing the look-ahead loads in the order the steady state would have issued them
+    // ("virtual steps" -LOOK..-1) makes the two states agree, so no turn starts with a pipeline drain.
+    f4 ring[R];
+    f4 qhal[PF], qpp[PF], qv2[PF], qps[PF], qim[PF];
+    constexpr int NV = LOOK > PF ? LOOK : PF;
+    static_for<2 * H>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        ring[k] = load_p(xa - H + k);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    static_for<NV>([&](auto JJ) {
+        constexpr int j = decltype(JJ)::value - NV;   // virtual step -NV .. -1
+        if constexpr (j >= -LOOK) ring[j + 2 * H + LOOK] = load_p(xa + j + H + LOOK);
+        if constexpr (j >= -PF) {
+            constexpr int m = j + PF;
+            const int row = min(xa + m, xe - 1);
+            qhal[m] = load_halo(row);
+            if constexpr (!LAPONLY) {
+                qpp[m] = load_plain(a.pp, row);
+                qv2[m] = load_plain(a.v2, row);
+            }
+            if constexpr (IMG) {
+                qps[m] = load_plain(a.psrc, row);
+                qim[m] = load_plain(a.img, row);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    if (wave_tap) {   // the first 2H window rows never "enter" the window during the march: damp them here
+        static_for<2 * H>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            taper_row(ring[k], tzc, znc, xa - H + k);
+        });
+    }
+
+    // One row of the march.  GUARD=false: the row is known to exist; GUARD=true: wave-uniform test.
+    auto row_step = [&](const int rb, auto UU, auto GG) {
+        constexpr int U = decltype(UU)::value;
+        constexpr bool GUARD = decltype(GG)::value;
+        constexpr int Q = U % PF;          // pointwise queue slot of this row (R % PF == 0)
+        const int r = rb + U;
+        if (!GUARD || r < xe) {
+            // ---- damping of what enters the computation this step -----------------------------
+            f4 hal = qhal[Q];
+            f4 ppt = qpp[Q];
+            if (wave_tap) {
+                taper_row(ring[(U + 2 * H) % R], tzc, znc, r + H);   // row r+H enters the window
+                taper_row(hal, tzh, znh, r);
+                if constexpr (!LAPONLY) {
+                    taper_row(ppt, tzc, znc, r);
+                    if (a.pp_twice) taper_row(ppt, tzc, znc, r);
+                }
+            }
+            // ---- z neighbours from the adjacent lanes (ds_bpermute), strip halo at the ends ----
+            const f4 c = ring[(U + H) % R];
+            f4 lft, rgt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#if FDW_ABL_BITS & 8
+                lft.v[e] = c.v[e] + hal.v[e];
+                rgt.v[e] = c.v[e] - hal.v[e];
+#else
+                const float up = __shfl_up(c.v[e], 1, 64), dn = __shfl_down(c.v[e], 1, 64);
+                lft.v[e] = lane_first ? hal.v[e] : up;
+                rgt.v[e] = lane_last ? hal.v[e] : dn;
+#endif
+            }
+            const bool rowok = (r >= a.lap_x0) && (r < a.lap_x1);
+            f4 res, imr;
+            if constexpr (DD) {
+                if (rec_here && r >= a.rec_x0 && r < a.rec_x0 + a.rec_n) {      // the trace sample of this step: the current field at depth rec_z
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (z0 + e == a.rec_z) a.rec[r - a.rec_x0] = c.v[e];      // interior point: its damping factors are 1.0f
+                }
+                float W[12];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { W[e] = lft.v[e]; W[4 + e] = c.v[e]; W[8 + e] = rgt.v[e]; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float col[2 * H + 1];
+#pragma unroll
+                    for (int io = 0; io <= 2 * H; ++io) col[io] = ring[(U + io) % R].v[e];
+                    float lap = laplacian_dd_pt<H>(W, e, col, a.cz, a.dx2inv, a.dz2inv);
+                    if (zedge || xedge) lap = (rowok && mlap[e]) ? lap : 0.0f;
+                    const float upd = leapfrog_prod(c.v[e], ppt.v[e], (qv2[Q].v[e] * a.dt2) * lap);
+                    res.v[e] = zedge ? (mupd[e] ? upd : ppt.v[e]) : upd;
+                }
+            } else {
+                // packed pairs: same products and sums in the same order as laplacian_pt (see laplacian_pair)
+                const ZPairs zp = zpairs(lft, c, rgt);
+                static_for<2>([&](auto PP) {
+                    constexpr int P = decltype(PP)::value;
+                    v2f lap2 = laplacian_pair<H, P>(zp, [&](auto IO) { return f4_pair(ring[(U + decltype(IO)::value) % R], P); }, cpk);
+                    if (zedge || xedge) lap2 = v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
+                    if constexpr (LAPONLY) {
+                        res.v[2 * P] = lap2.x;
+                        res.v[2 * P + 1] = lap2.y;
+                    } else {
+                        const v2f prod2 = (f4_pair(qv2[Q], P) * a.dt2) * lap2;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int e = 2 * P + q;
+                            const float upd = leapfrog_prod(c.v[e], ppt.v[e], q ? prod2.y : prod2.x);
+                            res.v[e] = zedge ? (mupd[e] ? upd : ppt.v[e]) : upd;
+                        }
+                    }
+                });
+            }
+            if constexpr (INJ != 0) {
+                if (inj_here) {   // wave-uniform, rare
+                    const bool injrow = (INJ == 1) ? (r == a.inj_x) : ((r >= a.inj_x) && (r < a.inj_x + a.inj_n));
+                    if (injrow) {
+                        const float injv = (INJ == 1) ? inj_src : sload(a.inj, r - a.inj_x);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) res.v[e] = ihit[e] ? res.v[e] + injv : res.v[e];
+                    }
+                }
+            }
+            if constexpr (INJ == 3) {
+                if (inj_here && r >= a.inj_x - 3 && r <= a.inj_x + 3) {   // ptsrc.c:49-55: s += ts * exp(-xn*xn - zn*zn), all float
+                    const int dxa = r > a.inj_x ? r - a.inj_x : a.inj_x - r;
+                    const float g0 = a.gw[dxa][0], g1 = a.gw[dxa][1], g2 = a.gw[dxa][2], g3 = a.gw[dxa][3];   // wave-uniform kernarg reads
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int dz = z0 + e - a.inj_z, dza = dz < 0 ? -dz : dz;
+                        const float g = dza == 0 ? g0 : (dza == 1 ? g1 : (dza == 2 ? g2 : g3));
+                        if (dza <= 3) res.v[e] = res.v[e] + inj_src * g;
+                    }
+                }
+            }
+            if constexpr (IMG) {
+                // kernel_img (R:133-144) correlates with the NEW receiver field; the sibling's rtm_main stores the CURRENT one
+                // (rwf[it] = P, rtm_main.cpp:211-215), an interior point of which carries damping factors of exactly 1.0f
+#pragma unroll
+                for (int e = 0; e < 4; ++e) imr.v[e] = qim[Q].v[e] + qps[Q].v[e] * (DD ? c.v[e] : res.v[e]);
+            }
+#if FDW_ABL_BITS & (4 | 32)
+            if (res.v[0] == 123.456f)
+#endif
+            if (!partial) {
+                f4_store(a.pp + (size_t)r * pitch, voff, res);
+                if constexpr (IMG) f4_store(a.img + (size_t)r * pitch, voff, imr);
+            } else if (act) {
+                f4_store(a.pp + (size_t)r * pitch, voff, res);
+                if constexpr (IMG) f4_store(a.img + (size_t)r * pitch, voff, imr);
+            }
+
+            // ---- refill the slots this row just freed (look-ahead loads) ----------------------
+            ring[U] = load_p(r - H + R);
+            {
+                const int nr = min(r + PF, xe - 1);
+                qhal[Q] = load_halo(nr);
+                if constexpr (!LAPONLY) {
+                    qpp[Q] = load_plain(a.pp, nr);
+                    qv2[Q] = load_plain(a.v2, nr);
+                }
+                if constexpr (IMG) {
+                    qps[Q] = load_plain(a.psrc, nr);
+                    qim[Q] = load_plain(a.img, nr);
+                }
+            }
+        }
+        // keep the look-ahead loads where they were issued: without this the machine scheduler
+        // sinks each load to one row before its first use to save registers, which turns the
+        // software prefetch into a load-use stall every row
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    int rb = xa;
+    // bulk: whole turns of the ring, no tests, exact s_waitcnt bookkeeping
+    for (; rb + R <= xe; rb += R)
+        static_for<R>([&](auto UU) { row_step(rb, UU, std::false_type{}); });
+    // remaining rows (< R)
+    if (rb < xe)
+        static_for<R>([&](auto UU) { row_step(rb, UU, std::true_type{}); });
+}
+
+template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false>
+__global__ __launch_bounds__(256) void fdw_step_kernel(const StepArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD
+    // a contiguous run of logical blocks = a contiguous band of x rows whose chunk halos it re-reads
+    // from its own L2.  Placement only changes speed, never results.
+    const int bid = blockIdx.x;
+    const int L = (bid & 7) * a.nper + (bid >> 3);
+    if (L >= a.nblk) return;
+    const int zb = L % a.nzblk;
+    const int xb = L / a.nzblk;
+    const int wz = a.wz;              // waves of a block laid along z: 1, 2 or 4
+    const int strip = zb * wz + (w & (wz - 1));
+    const int chunk = xb * (4 / wz) + (w / wz);
+    const int zs = strip * 256;       // first z of this wave's strip
+    if (zs >= a.pitch) return;
+    const int xa = a.r0 + chunk * a.xchunk;
+    const int xe = min(xa + a.xchunk, a.r1);
+    if (xa >= xe) return;
+    march<H, TAPER, INJ, IMG, LAPONLY, PF, DD>(a, lane, zs, xa, xe);
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic-order kernel: any even order up to FDW_MAX_ORDER, one thread per point, every tap from
+// global memory (L1/L2 absorb the reuse).  Same arithmetic, same lazy-taper rules; used for orders
+// the register-ring kernel is not instantiated for, and as an independent cross-check of it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float generic_p(const StepArgs& a, int row, int z, bool taper)
+{
+    float v = a.p[(size_t)row * a.pitch + z];
+    if (taper && z < a.ztap) v = taper1(v, a.taperz[z], true, row < a.tz_x1, a.txfac[row]);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void fdw_generic_kernel(const StepArgs a, int h, int taper, int injmode,
+                                                          int img, int laponly)
+{
+    const int z = blockIdx.x * 256 + threadIdx.x;
+    const int r = a.r0 + blockIdx.y;
+    if (z >= a.pitch || r >= a.r1) return;
+    const size_t k = (size_t)r * a.pitch + z;
+    float lap = 0.0f;
+    if (r >= a.lap_x0 && r < a.lap_x1 && z >= a.lap_z0 && z < a.lap_z1) {
+        float acmz = 0.0f, acmx = 0.0f;
+        for (int io = 0; io <= 2 * h; ++io) {
+            acmz = acmz + generic_p(a, r, z + io - h, taper) * a.gcz[io];
+            acmx = acmx + generic_p(a, r + io - h, z, taper) * a.gcx[io];
+        }
+        lap = acmz + acmx;
+    }
+    float out;
+    if (laponly) {
+        out = lap;
+    } else {
+        const float pc = generic_p(a, r, z, taper);
+        float ppv = a.pp[k];
+        if (taper && z < a.ztap) {
+            const bool rowtz = r < a.tz_x1;
+            const float txr = a.txfac[r], tz = a.taperz[z];
+            ppv = taper1(ppv, tz, true, rowtz, txr);
+            if (a.pp_twice) ppv = taper1(ppv, tz, true, rowtz, txr);
+        }
+        const float upd = leapfrog_pt(pc, ppv, a.v2[k], a.dt2, lap);
+        out = (z < a.upd_z1) ? upd : ppv;
+        if (injmode == 1) {
+            if (r == a.inj_x && z == a.inj_z) out = out + a.inj[0];
+        } else if (injmode == 2) {
+            if (r >= a.inj_x && r < a.inj_x + a.inj_n && z == a.inj_z) out = out + a.inj[r - a.inj_x];
+        }
+    }
+    a.pp[k] = out;
+    if (img) a.img[k] = a.img[k] + a.psrc[k] * out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the one T() the lazy scheme owes d_p before it leaves the device (fd_forward's D2H of d_p, R:285)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fdw_taper_finalize_kernel(float* f, const float* taperz, const float* txfac,
+                                                                 int pitch, int nxl, int ztap, int tz_x1)
+{
+    const int z = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (z >= ztap || z >= pitch || r >= nxl) return;
+    const size_t k = (size_t)r * pitch + z;
+    f[k] = taper1(f[k], taperz[z], true, r < tz_x1, txfac[r]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// device self test of the two hardware behaviours the kernels rely on:
+//   out[0..63]    = __shfl_up(src, 1)     (lane 0 keeps its own value)
+//   out[64..127]  = __shfl_down(src, 1)   (lane 63 keeps its own value)
+//   out[128..383] = a 64 x float4 row written with the range-predicated buffer store: lanes 2..61 store at
+//                   their own offset, the others at 0xFFFFFFF0 and must be dropped by the descriptor check
+// ------------------------------------------------------------------------------------------------
+// Image post-processing: the second-order Laplacian filter of laplace.f90:25-29 on a dense [nx][nz] image, in the
+// order the Fortran expression spells, frame left at zero.  HBM bound and tiny (one read, one write per point).
+__global__ __launch_bounds__(256) void fdw_image_lap_kernel(const float* img, float* out, int nx, int nz, float dx, float dz)
+{
+    const int iz = blockIdx.x * 256 + threadIdx.x, ix = blockIdx.y;
+    if (iz >= nz) return;
+    const size_t k = (size_t)ix * nz + iz;
+    float r = 0.0f;
+    if (ix >= 1 && ix < nx - 1 && iz >= 1 && iz < nz - 1) {
+        const float c = img[k];
+        r = ((img[k + 1] - 2.0f * c) + img[k - 1]) / (dz * dz) + ((img[k + nz] - 2.0f * c) + img[k - nz]) / (dx * dx);
+    }
+    out[k] = r;
+}
+
+__global__ void fdw_selftest_kernel(const float* src, float* out)
+{
+    const int t = threadIdx.x;
+    out[t] = __shfl_up(src[t], 1, 64);
+    out[64 + t] = __shfl_down(src[t], 1, 64);
+    f4 v;
+    v.v[0] = v.v[1] = v.v[2] = v.v[3] = src[t];
+    const unsigned off = (t >= 2 && t <= 61) ? (unsigned)t * 16u : 0xFFFFFFF0u;
+    f4_store_rsrc(out + 128, 64u * 16u, off, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+template <int H, int PF>
+static hipError_t launch_fast_hp(const StepArgs& a, int mode, hipStream_t s)
+{
+    const dim3 grid(8 * a.nper), block(256);
+    switch (mode) {
+    case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_step_kernel<H, true, 1, false, false, PF>), grid, block, 0, s, a); break;
+    case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_step_kernel<H, false, 0, false, false, PF>), grid, block, 0, s, a); break;
+    case FDW_MODE_RECV:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, PF>), grid, block, 0, s, a); break;
+    case FDW_MODE_LAP:   hipLaunchKernelGGL((fdw_step_kernel<H, false, 0, false, true, PF>), grid, block, 0, s, a); break;
+    case FDW_MODE_MOD:   hipLaunchKernelGGL((fdw_step_kernel<H, true, 3, false, false, PF, true>), grid, block, 0, s, a); break;
+    case FDW_MODE_DD_FWD:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 1, false, false, PF, true>), grid, block, 0, s, a); break;
+    case FDW_MODE_DD_RECV: hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, PF, true>), grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_step_fast(const StepArgs& a, int h, int mode, int pf, hipStream_t s)
+{
+    if (a.nper <= 0) return hipSuccess;
+    if (h == 4) {
+        switch (pf) {
+        case 1: return launch_fast_hp<4, 1>(a, mode, s);
+        case 3: return launch_fast_hp<4, 3>(a, mode, s);
+        default: return launch_fast_hp<4, 2>(a, mode, s);
+        }
+    }
+    switch (h) {
+    case 1: return launch_fast_hp<1, 2>(a, mode, s);
+    case 2: return launch_fast_hp<2, 2>(a, mode, s);
+    case 3: return launch_fast_hp<3, 2>(a, mode, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_step_generic(const StepArgs& a, int h, int mode, hipStream_t s)
+{
+    if (a.r1 <= a.r0) return hipSuccess;
+    const dim3 grid((a.pitch + 255) / 256, a.r1 - a.r0), block(256);
+    const int taper = (mode == FDW_MODE_FWD || mode == FDW_MODE_RECV);
+    const int inj = (mode == FDW_MODE_FWD) ? 1 : (mode == FDW_MODE_RECV ? 2 : 0);
+    hipLaunchKernelGGL(fdw_generic_kernel, grid, block, 0, s, a, h, taper, inj, mode == FDW_MODE_RECV ? 1 : 0,
+                       mode == FDW_MODE_LAP ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_taper_finalize(float* f, const float* taperz, const float* txfac, int pitch, int nxl, int ztap,
+                                 int tz_x1, hipStream_t s)
+{
+    if (ztap <= 0 || nxl <= 0) return hipSuccess;
+    const dim3 grid((ztap + 255) / 256, nxl), block(256);
+    hipLaunchKernelGGL(fdw_taper_finalize_kernel, grid, block, 0, s, f, taperz, txfac, pitch, nxl, ztap, tz_x1);
+    return hipGetLastError();
+}
+
+hipError_t launch_image_laplacian(const float* d_img, float* d_out, int nx, int nz, float dx, float dz, hipStream_t s)
+{
+    hipLaunchKernelGGL(fdw_image_lap_kernel, dim3((nz + 255) / 256, nx), dim3(256), 0, s, d_img, d_out, nx, nz, dx, dz);
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest(const float* src, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(fdw_selftest_kernel, dim3(1), dim3(64), 0, s, src, out);
+    return hipGetLastError();
+}
+
+}  // namespace fdw

@@ -1,0 +1,291 @@
+// fdw_stepn.hip -- four time steps per pass: a pipeline of waves through LDS.  Shared helpers and design notes: fdw_device.h.
+#include "fdw_device.h"
+
+#pragma clang fp contract(off)
+
+namespace fdw {
+
+// ------------------------------------------------------------------------------------------------
+// NS time steps per pass: a pipeline of NS waves per workgroup, one wave per time level, rows handed from
+// wave to wave through LDS.  Wave k (k = 0..NS-1) computes u^{n+k+1}; only wave 0 reads global memory
+// (u^n, u^{n-1}, v2) and only the last two waves write it (u^{n+NS-1} -> out1, u^{n+NS} -> out2), so a
+// pass moves 12 B in + 8 B out per point for NS steps instead of per step.
+//
+// Every wave is the one-step march on a register ring of 2H+1 rows of "its" p field.  At march step m wave k
+// works on row r_k(m) = xa - (NS-1)H - k(H+1) + m: a skew of H+1 rows per stage, so that what wave k-1
+// produced during step m-1 (its result row r_{k-1}(m-1) = r_k(m)+H, which enters wave k's window, and the
+// row its own window dropped, r_{k-1}(m-1)-H = r_k(m), which is wave k's "pp") is consumed during step m;
+// one workgroup barrier per march step separates producer and consumer, link buffers alternate by the parity
+// of m.  v2 rows ride a 16-row LDS FIFO filled by wave 0.  All waves run IDENTICAL code: the global loads of
+// waves k > 0 are sent out of range through the buffer descriptor (no memory request, zeros returned) and the
+// stores of waves < NS-2 likewise, so the s_waitcnt counting stays exact and nothing diverges.
+// Validity: wave k's rows are good from march step k(2H+1) on (its window then holds only good rows of wave
+// k-1); in z every step costs H = one lane per side, so NS lanes per side of a wave are halo and 64-2NS owned.
+// Per point and step the arithmetic is the one-step kernel's (packed pairs as in the two-step kernel).
+// ------------------------------------------------------------------------------------------------
+#ifndef FDW_PIPE_PF
+#define FDW_PIPE_PF 2      // rows of global look-ahead of wave 0
+#endif
+#ifndef FDW_PIPE_ROWS
+#define FDW_PIPE_ROWS 1    // march steps between two workgroup barriers of the pipeline kernel (1 or 2)
+#endif
+// v2 FIFO depth: the last wave reads row m - (NS-1)(H+ROWS) while wave 0 writes rows m .. m+ROWS-1
+constexpr int pipe_fifo_rows(int ns, int h, int rows) { return rows == 1 ? 16 : (ns - 1) * (h + rows) + rows; }
+template <int FD>
+__device__ __forceinline__ int pipe_fifo_slot(int m)
+{
+    if constexpr ((FD & (FD - 1)) == 0) return m & (FD - 1);
+    else return ((m % FD) + FD) % FD;
+}
+
+template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int ROWS = FDW_PIPE_ROWS>
+__device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const int k, const int cs, const int xa, const int xe,
+                                       f4 (*link)[2][2][ROWS][64], f4 (*fifo)[64])
+{
+    // ROWS march steps between two workgroup barriers (1 or 2): a wave consumes what its predecessor produced during the previous
+    // ROWS steps, so consecutive waves work H + ROWS rows apart and a wave's first good row comes ROWS later per stage.
+    constexpr int R = ((2 * H + PF + PF - 1) / PF) * PF;
+    constexpr int LOOK = R - 2 * H;
+    constexpr int SK = H + ROWS;
+    constexpr int FD = pipe_fifo_rows(NS, H, ROWS);
+    static_assert(ROWS == 1 || (ROWS == 2 && R % 2 == 0), "one or two rows per barrier");
+    const bool first = (k == 0);
+    const int cell = cs + lane;
+    const int z0 = cell * 4;
+    const unsigned voff = (unsigned)min(max(z0, 0), a.pitch - 4) * 4u;
+    const bool own = (lane >= NS) && (lane <= 63 - NS) && (z0 >= 0) && (z0 < a.pitch);
+    const unsigned soff = (own && k >= NS - 2) ? voff : kLaneOff;         // only the last two waves store
+    const unsigned loff = first ? voff : kLaneOff;                        // only wave 0 loads
+    const unsigned row_bytes = (unsigned)a.pitch * 4u;
+    const int rowmax = a.nxl - 1;
+    const unsigned arr_bytes = (unsigned)a.nxl * row_bytes;               // < 2 GiB (checked by the host)
+    const __amdgpu_buffer_rsrc_t rs_p = array_rsrc(a.p, arr_bytes), rs_pp = array_rsrc(a.pp, arr_bytes), rs_v2 = array_rsrc(a.v2, arr_bytes);
+    const __amdgpu_buffer_rsrc_t rs_out = array_rsrc((k == NS - 1) ? a.out2 : a.out1, arr_bytes);
+
+    const bool wave_tap = TAPER && (cs * 4 < a.ztap);
+    const bool xtap = wave_tap && ((xa - NS * H < a.xt_lo) || (xe + NS * H > a.xt_hi));
+    const CoefPairs<H> cpk = coef_pairs<H>(a.cx, a.cz);
+    const int blob = (INJ == 3) ? 3 : 0;                                  // INJ 3: 7x7 Gaussian source of the CPU-serial sibling (ptsrc.c:49-55)
+    const bool inj_here = (INJ != 0) && (a.inj_z + blob >= cs * 4) && (a.inj_z - blob < cs * 4 + 256) && (a.inj_x + blob >= xa - NS * H) && (a.inj_x - blob < xe + NS * H);
+    const float injv = inj_here ? sload(a.inj, k) : 0.0f;                 // source sample of this wave's time step (R:119-122)
+    const bool rec_here = DD && (a.rec != nullptr) && (a.rec_z >= cs * 4) && (a.rec_z < cs * 4 + 256);
+
+    bool mlap[4], mupd[4], znc[4], ihit[4];
+    float tzc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int z = z0 + e;
+        mlap[e] = (z >= a.lap_z0) && (z < a.lap_z1);
+        mupd[e] = (z >= 0) && (z < a.upd_z1);
+        ihit[e] = (z == a.inj_z);
+        znc[e] = (z >= 0) && (z < a.ztap);
+        tzc[e] = 1.0f;
+    }
+    if (wave_tap) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (znc[e]) tzc[e] = a.taperz[z0 + e];
+    }
+    auto taper_row = [&](f4& v, int row) {
+        if (!xtap) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = v.v[e] * tzc[e];
+        } else {
+            const int rc = min(max(row, 0), a.nxl - 1);
+            const float txr = sload(a.txfac, rc);
+            const bool rowtz = row < a.tz_x1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v.v[e] = taper1(v.v[e], tzc[e], znc[e], rowtz, txr);
+        }
+    };
+    auto rowoff = [&](int row) -> unsigned { return (unsigned)min(max(row, 0), rowmax) * row_bytes; };
+    auto load_p = [&](int row) -> f4 { return f4_load_arr(rs_p, loff, rowoff(row), (FDW_NT & 4) != 0); };
+    auto load_pw = [&](__amdgpu_buffer_rsrc_t rs, int row) -> f4 { return f4_load_arr(rs, loff, rowoff(row), (FDW_NT & 1) != 0); };
+
+    // rows: wave 0's centre row at march step m is s0 + m (what the global loads follow); this wave's is rk + m
+    const int s0 = xa - (NS - 1) * H, b0 = s0 - H;
+    const int rk = s0 - k * SK;
+    const int M = (xe - xa) + (NS - 1) * (2 * H + ROWS);
+    const int kp = max(k - 1, 0);
+    f4 ring[R];
+    f4 qpp[PF], qv2[PF];
+    constexpr int NV = LOOK > PF ? LOOK : PF;
+    static_for<2 * H>([&](auto K) {
+        constexpr int kk = decltype(K)::value;
+        ring[kk] = load_p(b0 + kk);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    static_for<NV>([&](auto JJ) {
+        constexpr int j = decltype(JJ)::value - NV;
+        if constexpr (j >= -LOOK) ring[j + 2 * H + LOOK] = load_p(b0 + j + 2 * H + LOOK);
+        if constexpr (j >= -PF) {
+            constexpr int mm = j + PF;
+            qpp[mm] = load_pw(rs_pp, s0 + mm);
+            qv2[mm] = load_pw(rs_v2, s0 + mm);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    if (wave_tap) {
+        static_for<2 * H>([&](auto K) {
+            constexpr int kk = decltype(K)::value;
+            taper_row(ring[kk], b0 + kk);
+        });
+    }
+
+    auto row_step = [&](const int mb, auto UU) {
+        constexpr int U = decltype(UU)::value;
+        constexpr int Q = U % PF;
+        constexpr int E = (U + 2 * H) % R;                      // slot of the row entering the window this step
+        const int m = mb + U;
+        const int r = rk + m;
+        constexpr int SLOT = U % ROWS;                          // which of the ROWS rows between two barriers
+        const int par = (m / ROWS) & 1;                          // link buffers alternate per barrier interval
+        // ---- what the previous wave handed over during march step m-1 ----
+#if FDW_ABL_BITS & 128
+        const f4 nr = ring[U], ppl = ring[(U + 1) % R], v2l = ring[(U + 2) % R];
+#else
+        const f4 nr = link[kp][par ^ 1][0][SLOT][lane];
+        const f4 ppl = link[kp][par ^ 1][1][SLOT][lane];
+        const f4 v2l = fifo[pipe_fifo_slot<FD>(m - k * SK)][lane];
+#endif
+        f4 ppt, v2t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ring[E].v[e] = first ? ring[E].v[e] : nr.v[e];
+            ppt.v[e] = first ? qpp[Q].v[e] : ppl.v[e];
+            v2t.v[e] = first ? qv2[Q].v[e] : v2l.v[e];
+        }
+#if !(FDW_ABL_BITS & 128)
+        if (first) fifo[pipe_fifo_slot<FD>(m)][lane] = qv2[Q];
+#endif
+        if (wave_tap) {
+            taper_row(ring[E], r + H);                          // entering row: damped once as "p" of this step
+            taper_row(ppt, r);                                  // "pp": from memory once (+ once owed), from LDS once more
+            if (first && a.pp_twice) taper_row(ppt, r);
+        }
+        const f4 c1 = ring[(U + H) % R];
+        f4 lft, rgt;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#if FDW_ABL_BITS & 2048
+            lft.v[e] = c1.v[(e + 1) & 3]; rgt.v[e] = c1.v[(e + 2) & 3];
+#else
+            lft.v[e] = __shfl_up(c1.v[e], 1, 64);
+            rgt.v[e] = __shfl_down(c1.v[e], 1, 64);
+#endif
+        }
+        const bool rowok = (r >= a.lap_x0) && (r < a.lap_x1);
+        const bool rowupd = (r >= 0) && (r < a.upd_x1);
+        f4 u;
+        if constexpr (DD) {
+            // this wave's p field is P of iteration it0 + k: its trace sample (mod_main.cpp:155-157); owned lanes and rows only
+            if (rec_here && own && r >= xa && r < xe && r >= a.rec_x0 && r < a.rec_x0 + a.rec_n) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (z0 + e == a.rec_z) a.rec[k * a.rec_n + (r - a.rec_x0)] = c1.v[e];
+            }
+            float W[12];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { W[e] = lft.v[e]; W[4 + e] = c1.v[e]; W[8 + e] = rgt.v[e]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float col[2 * H + 1];
+#pragma unroll
+                for (int io = 0; io <= 2 * H; ++io) col[io] = ring[(U + io) % R].v[e];
+                float lap = laplacian_dd_pt<H>(W, e, col, a.cz, a.dx2inv, a.dz2inv);
+                lap = (rowok && mlap[e]) ? lap : 0.0f;
+                const float upd = leapfrog_prod(c1.v[e], ppt.v[e], (v2t.v[e] * a.dt2) * lap);
+                u.v[e] = (rowupd && mupd[e]) ? upd : ppt.v[e];
+            }
+        } else {
+            const ZPairs zp = zpairs(lft, c1, rgt);
+            v2f lapq[2];
+            laplacian_quad<H>(zp, [&](auto IO) -> const f4& { return ring[(U + decltype(IO)::value) % R]; }, cpk, lapq[0], lapq[1]);
+            static_for<2>([&](auto PP) {
+                constexpr int P = decltype(PP)::value;
+                const v2f lap2 = lapq[P];
+                const v2f prod2 = (f4_pair(v2t, P) * a.dt2) * v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = 2 * P + q;
+                    const float upd = leapfrog_prod(c1.v[e], ppt.v[e], q ? prod2.y : prod2.x);
+                    u.v[e] = (rowupd && mupd[e]) ? upd : ppt.v[e];
+                }
+            });
+        }
+        if constexpr (INJ == 1) {
+            if (inj_here && r == a.inj_x) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u.v[e] = ihit[e] ? u.v[e] + injv : u.v[e];
+            }
+        }
+        if constexpr (INJ == 3) {
+            if (inj_here && r >= a.inj_x - 3 && r <= a.inj_x + 3) {
+                const int dxa = r > a.inj_x ? r - a.inj_x : a.inj_x - r;
+                const float g0 = a.gw[dxa][0], g1 = a.gw[dxa][1], g2 = a.gw[dxa][2], g3 = a.gw[dxa][3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int dz = z0 + e - a.inj_z, dza = dz < 0 ? -dz : dz;
+                    const float g = dza == 0 ? g0 : (dza == 1 ? g1 : (dza == 2 ? g2 : g3));
+                    if (dza <= 3) u.v[e] = u.v[e] + injv * g;
+                }
+            }
+        }
+        // ---- hand over to the next wave: the new row (raw) and the row leaving this window (damped once) ----
+#if !(FDW_ABL_BITS & 128)
+        link[k][par][0][SLOT][lane] = u;
+        link[k][par][1][SLOT][lane] = ring[U];
+#endif
+        const unsigned so = ((r >= xa) && (r < xe) && (m < M)) ? soff : kLaneOff;
+#if FDW_ABL_BITS & 1024
+        ring[U] = u;
+#else
+        f4_store_arr(rs_out, so, rowoff(r), u);
+        // ---- look-ahead loads of wave 0 into the slots this step freed ----
+        ring[U] = load_p(b0 + m + R);
+        qpp[Q] = load_pw(rs_pp, s0 + m + PF);
+        qv2[Q] = load_pw(rs_v2, s0 + m + PF);
+#endif
+#if !(FDW_ABL_BITS & 64)
+        if constexpr (SLOT == ROWS - 1) __syncthreads();
+#endif
+    };
+
+    for (int mb = 0; mb < M; mb += R)
+        static_for<R>([&](auto UU) { row_step(mb, UU); });
+}
+
+template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false>
+__global__ __launch_bounds__(64 * NS, FDW_PIPE_ROWS != 1 ? 3 : (DD ? 4 : 5)) void fdw_stepn_kernel(const Step2Args a)
+{
+    const int lane = threadIdx.x & 63;
+    const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bid = blockIdx.x;
+    const int L = (bid & 7) * a.nper + (bid >> 3);
+    if (L >= a.nblk) return;                    // whole workgroups only: every barrier below is reached by all NS waves
+    const int zb = L % a.nstrip;
+    const int xb = L / a.nstrip;
+    const bool second = xb >= a.chunks_a;       // two row ranges in one launch (the two boundary strips of a slab)
+    const int xa = second ? a.r0b + (xb - a.chunks_a) * a.xchunk : a.r0 + xb * a.xchunk;
+    const int xe = min(xa + a.xchunk, second ? a.r1b : a.r1);
+    if (xa >= xe) return;
+    __shared__ f4 link[NS][2][2][FDW_PIPE_ROWS][64];       // [producer wave][parity][0 new row | 1 row leaving the window][row of the interval][lane]
+    __shared__ f4 fifo[pipe_fifo_rows(NS, H, FDW_PIPE_ROWS)][64];
+    marchn<H, NS, TAPER, INJ, PF, DD>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo);
+}
+
+hipError_t launch_stepn(const Step2Args& a, int h, int mode, hipStream_t s)
+{
+    if (a.nper <= 0) return hipSuccess;
+    if (h != 4) return hipErrorInvalidValue;
+    const dim3 grid(8 * a.nper), block(64 * kPipeSteps);
+    switch (mode) {
+    case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 1, FDW_PIPE_PF>), grid, block, 0, s, a); break;
+    case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, false, 0, FDW_PIPE_PF>), grid, block, 0, s, a); break;
+    case FDW_MODE_MOD:   hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 3, FDW_PIPE_PF, true>), grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace fdw

@@ -12,7 +12,7 @@ h*(ksteps-1)/2 rows per side per step; in exchange the per-step collective (a 2x
 ~25 us step, latency bound over xGMI) becomes one 2*G-row message every ksteps steps.
 
 Both time levels travel (leap-frog state is the pair (p, pp)); what is exchanged is the raw memory
-state of the owner's rows, so the "lazy taper" bookkeeping of the kernels (fdw_kernels.hip) stays a
+state of the owner's rows, so the "lazy taper" bookkeeping of the kernels (csrc/fdw_device.h) stays a
 pure function of (memory, step index) on every rank.  Arithmetic per point is unchanged, hence the
 decomposed result is bit-identical to the single-slab result.
 
