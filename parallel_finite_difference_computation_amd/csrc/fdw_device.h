@@ -21,8 +21,10 @@
 //   * every global load of the march is unconditional (clamped addresses instead of predication) so
 //     that hipcc's s_waitcnt bookkeeping stays exact (vmcnt(4..7), never 0); edge handling is
 //     wave-uniform branches around VALU / scalar-cache loads only;
-//   * fdw_step2_kernel does TWO time steps per pass (temporal blocking, 10 B/point/step): overlapped
-//     60-cell tiles, a second register ring for u^{n+1}, v2 rows parked in LDS, range-predicated stores.
+//   * fdw_step2_kernel (fdw_step2.hip) does TWO time steps per pass (temporal blocking, 10 B/point/step): overlapped
+//     60-cell tiles, a second register ring for u^{n+1}, v2 rows parked in LDS, range-predicated stores;
+//   * fdw_stepn_kernel (fdw_stepn.hip) does FOUR: a workgroup is a pipeline of four waves, one per time level, rows
+//     handed from wave to wave through LDS, one barrier per march step (5 B/point/step; the kernel the headline bench runs).
 //
 // Arithmetic is the reference's, operation for operation, so results are IEEE-identical to the
 // no-FMA CUDA build (nvcc --fmad=false --ftz=false, Makefile:4): two fp32 accumulators summed
