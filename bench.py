@@ -129,6 +129,39 @@ def run_model_workload(args):
         sys.exit("bench: result is not finite / all zero")
 
 
+def run_rtm_workload(args):
+    """`--workload rtm`: BASELINE.json's third configuration -- one RTM shot (fd_forward + fd_back with imaging, fd-code.cu:496-518) on the
+    reference's own deck size (models/new_mod: 415 x 295 extended grid, nt = 1700) through the host-array entry point fdw_shot, i.e.
+    including the uploads and the image download a drop-in `rtm_code` pays per shot.  value = field updates per second: per time index one
+    forward step, one source-field reconstruction step and one receiver step."""
+    nxe, nze, nxb, nzb, nt = 415, 295, 50, 50, 1700
+    K, W = max(1, args.steps // 100), 1                 # shots timed / warm-up shots (a shot is 3 * nt kernel launches)
+    ctx = F.FDWave(ORDER, nxe, nze, nxb, nzb, nt, 0.75, DX, DX, DT, compat=True)
+    rng = np.random.default_rng(0)
+    v2 = ((1500.0 + 2500.0 * rng.random((nxe, nze))) ** 2).astype(np.float32)
+    srce = F.ricker_wavelet(nt, DT, FPEAK)
+    d_obs = rng.standard_normal((nxe - 2 * nxb, nt)).astype(np.float32)
+    for _ in range(W):
+        img = ctx.shot(v2, nxe // 2, nzb, nzb, srce, d_obs)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        img = ctx.shot(v2, nxe // 2, nzb, nzb, srce, d_obs)
+    wall = time.perf_counter() - t0
+    upd = 3.0 * nt * nxe * nze * K
+    out = {"metric": "Gpoints/s (stencil updates) + achieved HBM GB/s vs peak", "value": round(upd / wall / 1e9, 3), "unit": "Gpoints/s", "n_gpus": 1,
+           "steps": K, "warmup": W, "ms_per_step": round(wall * 1e3 / K, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic (random velocity model and gather)",
+           "config": {"workload": f"one RTM shot per step (forward {nt} + backward {nt} iterations with imaging) on the new_mod deck size, "
+                                  f"{nxe}x{nze} extended grid, host arrays in / image out (fdw_shot), {K} shots", "grid": [nxe, nze], "order": ORDER,
+                      "parallelism": "single"},
+           "result_finite_nonzero": bool(np.isfinite(img).all() and np.abs(img).max() > 0),
+           "roofline": {"bound": "hbm", "achieved": round(upd * 16 / wall / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(upd * 16 / wall / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel": "fdw::fdw_step_kernel<4,...> (one-step kernels: a 122k-point grid is launch/latency bound, 3 launches per time index)",
+                        "launch_us": round(wall * 1e6 / (3.0 * nt * K), 2), "steps_per_launch": 1, "algorithmic_bytes_per_launch": 16.0 * nxe * nze}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,8 +171,9 @@ def main():
     ap.add_argument("--ksteps", type=int, default=0, help="time steps per halo exchange (N > 1); 0 = auto")
     ap.add_argument("--pipe", choices=("auto", "on", "off"), default="auto",
                     help="N > 1: four-steps-per-pass wave-pipeline kernel inside the slabs (auto = where the library would pick it)")
-    ap.add_argument("--workload", choices=("forward", "model"), default="forward",
-                    help="forward: the headline fused forward step of rtm_code (default); model: the forward-modelling producer (N = 1 only)")
+    ap.add_argument("--workload", choices=("forward", "model", "rtm"), default="forward",
+                    help="forward: the headline fused forward step of rtm_code (default); model: the forward-modelling producer; "
+                         "rtm: whole RTM shots on the reference's new_mod deck size (both N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU rehearsals)")
@@ -147,12 +181,12 @@ def main():
     ap.add_argument("--init", choices=["noise", "rest"], default="noise",
                     help="initial wavefield: seeded noise (default; every cache line carries real data) or at rest (zeros + source)")
     args = ap.parse_args()
-    if args.workload == "model":
+    if args.workload != "forward":
         if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
-            sys.exit("bench --workload model runs on one GPU")
+            sys.exit(f"bench --workload {args.workload} runs on one GPU")
         if not torch.cuda.is_available():
             sys.exit("bench: no GPU visible (the product has no CPU path)")
-        return run_model_workload(args)
+        return run_model_workload(args) if args.workload == "model" else run_rtm_workload(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
