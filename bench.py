@@ -157,8 +157,9 @@ def run_rtm_workload(args):
            "result_finite_nonzero": bool(np.isfinite(img).all() and np.abs(img).max() > 0),
            "roofline": {"bound": "hbm", "achieved": round(upd * 16 / wall / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(upd * 16 / wall / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                        "kernel": "fdw::fdw_step_kernel<4,...> (one-step kernels: a 122k-point grid is launch/latency bound, 3 launches per time index)",
-                        "launch_us": round(wall * 1e6 / (3.0 * nt * K), 2), "steps_per_launch": 1, "algorithmic_bytes_per_launch": 16.0 * nxe * nze}}
+                        "kernel": "fdw::fdw_step_kernel<4,...> (one-step kernels: a 122k-point grid is launch/latency bound; 2 launches per time index: "
+                                  "forward step, fused backward iteration)",
+                        "launch_us": round(wall * 1e6 / (2.0 * nt * K), 2), "steps_per_launch": 1, "algorithmic_bytes_per_launch": 16.0 * nxe * nze}}
     print(json.dumps(out), flush=True)
 
 

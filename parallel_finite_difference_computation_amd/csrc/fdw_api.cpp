@@ -73,6 +73,7 @@ struct fdw_ctx {
     // tuning
     int xchunk = 0, wz = 0, use_generic = 0, prefetch = 0, force_edge = 0, xchunk2 = 0;
     int tb = 0;   // two-steps-per-pass kernel: 0 auto (large grids), 1 always, -1 never
+    int no_fused_back = 0;   // experiments / tests: backward iterations as two launches (source step, receiver step) -- FDW_NO_FUSED_BACK=1
 };
 
 static size_t field_elems(const fdw_ctx* c) { return (size_t)c->nxl * (size_t)c->pitch; }
@@ -177,6 +178,7 @@ extern "C" int fdw_create_slab(const fdw_params* prm, const fdw_slab* slab, int 
     c->nx = prm->nxe - 2 * prm->nxb;
     c->nz = prm->nze - 2 * prm->nzb;
     c->pitch = ((prm->nze + 63) / 64) * 64;  // 256-B aligned rows: every lane's float4 is aligned
+    if (const char* nf = getenv("FDW_NO_FUSED_BACK")) c->no_fused_back = atoi(nf);
     if (const char* pad = getenv("FDW_PITCH_PAD")) {   // experiment knob: extra floats per row (multiple of 4)
         const int extra = atoi(pad);
         if (extra > 0 && extra % 4 == 0) c->pitch += extra;
@@ -337,20 +339,22 @@ static void fill_geometry(const fdw_ctx* c, StepArgs& a, int rows)
 
 static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const float* d_v2, int r0, int r1,
                      int pp_twice, const float* d_inj, int inj_x_global, int inj_z, const float* d_psrc, float* d_img,
-                     hipStream_t s, float* d_rec_row = nullptr, int rec_z = 0)
+                     hipStream_t s, float* d_rec_row = nullptr, int rec_z = 0, float* d_fpp = nullptr)
 {
     const bool lap = (mode == FDW_MODE_LAP);
     if (!d_p || !d_pp) return fail(FDW_EINVAL, "step: field pointer is NULL");
     if (!lap && !d_v2) return fail(FDW_EINVAL, "step: v2 is NULL");
-    if ((mode == FDW_MODE_RECV || mode == FDW_MODE_DD_RECV) && (!d_psrc || !d_img || !d_inj)) return fail(FDW_EINVAL, "step: RECV needs d_inj, d_psrc and d_img");
-    if (mode < FDW_MODE_FWD || mode > FDW_MODE_DD_RECV) return fail(FDW_EINVAL, "step: unknown mode %d", mode);
-    const int mode_dialect = mode == FDW_MODE_MOD ? FDW_DIALECT_MOD : (mode >= FDW_MODE_DD_FWD ? FDW_DIALECT_RTM_STORED : FDW_DIALECT_RTM);
+    if ((mode == FDW_MODE_RECV || mode == FDW_MODE_DD_RECV || mode == FDW_MODE_BACK) && (!d_psrc || !d_img || !d_inj)) return fail(FDW_EINVAL, "step: RECV needs d_inj, d_psrc and d_img");
+    if (mode == FDW_MODE_BACK && (!d_fpp || d_fpp == d_pp || d_fpp == d_p || d_psrc == d_pp || c->h > kMaxFastHalfOrder || c->use_generic))
+        return fail(FDW_EINVAL, "step: BACK needs the older source field as a fourth, distinct buffer and an order <= 8");
+    if (mode < FDW_MODE_FWD || mode > FDW_MODE_BACK) return fail(FDW_EINVAL, "step: unknown mode %d", mode);
+    const int mode_dialect = mode == FDW_MODE_MOD ? FDW_DIALECT_MOD : ((mode == FDW_MODE_DD_FWD || mode == FDW_MODE_DD_RECV) ? FDW_DIALECT_RTM_STORED : FDW_DIALECT_RTM);
     if (mode_dialect != c->prm.dialect)
         return fail(FDW_ESTATE, "step: mode %d does not belong to this context's dialect %d", mode, c->prm.dialect);
     if (r0 < 0 || r1 > c->nxl || r0 > r1) return fail(FDW_EINVAL, "step: rows [%d,%d) outside the slab (%d rows)", r0, r1, c->nxl);
 
     StepArgs a{};
-    a.p = d_p; a.pp = d_pp; a.v2 = d_v2; a.psrc = d_psrc; a.img = d_img;
+    a.p = d_p; a.pp = d_pp; a.v2 = d_v2; a.psrc = d_psrc; a.img = d_img; a.fpp = d_fpp;
     a.taperz = c->d_taperz; a.txfac = c->d_txfac; a.inj = d_inj; a.gcx = c->d_gcx; a.gcz = c->d_gcz;
     a.pitch = c->pitch; a.nxl = c->nxl;
     a.r0 = r0;
@@ -361,7 +365,7 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
     a.ztap = c->ztap; a.tz_x1 = c->tz_x1; a.xt_lo = c->xt_lo; a.xt_hi = c->xt_hi;
     a.pp_twice = pp_twice ? 1 : 0;
     a.inj_x = -1; a.inj_z = inj_z; a.inj_n = 0;
-    if (mode >= FDW_MODE_DD_FWD) { a.dx2inv = c->dx2inv; a.dz2inv = c->dz2inv; }
+    if (mode == FDW_MODE_DD_FWD || mode == FDW_MODE_DD_RECV) { a.dx2inv = c->dx2inv; a.dz2inv = c->dz2inv; }
     if ((mode == FDW_MODE_FWD || mode == FDW_MODE_DD_FWD) && d_inj && inj_x_global >= 0) {
         if (inj_z < 0 || inj_z >= c->prm.nze || inj_x_global >= c->prm.nxe)
             return fail(FDW_EINVAL, "step: source (%d,%d) outside the grid", inj_x_global, inj_z);
@@ -382,7 +386,7 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
         a.rec = d_rec_row; a.rec_z = rec_z;
         a.rec_x0 = c->prm.nxb - c->slab.x_off; a.rec_n = c->nx;
         if (d_rec_row && (rec_z < 0 || rec_z >= c->prm.nze)) return fail(FDW_EINVAL, "step: receiver depth %d outside the grid", rec_z);
-    } else if (mode == FDW_MODE_RECV || mode == FDW_MODE_DD_RECV) {
+    } else if (mode == FDW_MODE_RECV || mode == FDW_MODE_DD_RECV || mode == FDW_MODE_BACK) {
         if (inj_z < 0 || inj_z >= c->prm.nze) return fail(FDW_EINVAL, "step: receiver depth %d outside the grid", inj_z);
         // receivers sit on interior columns nxb..nxb+nx-1 (R:126-129); clip to this slab.  The sibling's rtm_main offsets them by
         // nzb instead (PP[ix+nzb][gz], rtm_main.cpp:203) -- the same thing only when both borders are equally wide; kept as is.
@@ -405,7 +409,7 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
         fill_geometry(c, a, a.r1 - a.r0);
         e = launch_step_fast(a, c->h, mode, effective_prefetch(c), s);
     } else {
-        if (mode >= FDW_MODE_MOD) return fail(FDW_EINVAL, "step: dialects 1 and 2 have no generic-order kernel");
+        if (mode >= FDW_MODE_MOD) return fail(FDW_EINVAL, "step: mode %d has no generic-order kernel", mode);
         e = launch_step_generic(a, c->h, mode, s);
     }
     if (e != hipSuccess) return fail(FDW_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -879,7 +883,17 @@ static int back_loop(fdw_ctx* c, float* const src[4], float* const rcv[4], int g
             const float* F;
             if (it == 0) F = src[1];
             else if (it == 1) F = src[0];
-            else {
+            else if (c->h <= kMaxFastHalfOrder && !c->use_generic && !c->no_fused_back) {
+                // the whole iteration in ONE pass: the source field is stepped in place (F_k overwrites F_{k-2}) in the same kernel
+                // that steps the receiver field, and meets the new receiver row in registers for the imaging condition
+                if ((rc = step_impl(c, FDW_MODE_BACK, rcv[rn], rcv[ro], c->d_v2, 0, c->nxl, it > 0, samples(it), 0, gz, src[f1], c->d_img, c->stream,
+                                    nullptr, 0, src[f0])))
+                    return rc;
+                std::swap(f1, f0);
+                std::swap(rn, ro);
+                it += 1;
+                continue;
+            } else {
                 // one-step reconstruction in place: the new field overwrites F_{k-2}
                 if ((rc = step_impl(c, FDW_MODE_PLAIN, src[f1], src[f0], c->d_v2, 0, c->nxl, 0, nullptr, -1, 0, nullptr, nullptr, c->stream))) return rc;
                 std::swap(f1, f0);

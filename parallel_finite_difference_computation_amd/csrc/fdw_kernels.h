@@ -11,6 +11,7 @@ enum {
     FDW_MODE_LAP = 3,    // Laplacian only, written to `pp`                (stencil_code, S:325)
     FDW_MODE_MOD = 4,    // forward-modelling step of the CPU-serial sibling (mod_main: fd_step + ptsrc + taper_apply + trace sample)
     FDW_MODE_DD_FWD = 5, // its stored-wavefield RTM, source pass (rtm_main.cpp:165-184: fd_step + one-cell source + taper_apply2)
+    FDW_MODE_BACK = 7,   // one whole backward iteration of fd_back in a single pass: source-field step + receiver step + imaging (R:317-329)
     FDW_MODE_DD_RECV = 6 // its receiver pass (rtm_main.cpp:197-220) + img += stored source field * CURRENT receiver field (rtm_main.cpp:224-230)
 };
 
@@ -22,7 +23,8 @@ struct StepArgs {
     const float* p;        // [nxl][pitch] newest field (read only in this launch)
     float* pp;             // [nxl][pitch] older field, overwritten with the new one (or Laplacian out)
     const float* v2;       // [nxl][pitch] squared velocity
-    const float* psrc;     // IMG: source wavefield to correlate with
+    const float* psrc;     // IMG: source wavefield to correlate with; BACK: F_{k-1}, the newer source field (read only)
+    float* fpp;            // BACK: F_{k-2}, overwritten with the reconstructed F_k
     float* img;            // IMG: image accumulator on the extended grid
     const float* taperz;   // [ztap] z damping factors
     const float* txfac;    // [nxl] per-row x damping factor (1.0f where none applies)

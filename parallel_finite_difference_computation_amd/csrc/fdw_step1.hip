@@ -25,9 +25,13 @@ namespace fdw {
 // >= nze-H.  Edge handling (masks, damping, injection) is wave-uniform branches around VALU / scalar
 // loads only.
 // ------------------------------------------------------------------------------------------------
-template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false>
+template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false, bool BACK = false>
 __device__ __forceinline__ void march(const StepArgs& a, const int lane, const int zs, const int xa, const int xe)
 {
+    // BACK: one whole backward iteration of fd_back (R:317-329) in a single pass: the source field is reconstructed in a second
+    // register ring (a.psrc = F_{k-1} read only, a.fpp = F_{k-2} overwritten with F_k: kernel_lap + kernel_time without damping,
+    // R:317-318) next to the receiver step, v2 is read once for both and F_k meets the new receiver row in registers for the imaging
+    // condition instead of travelling through memory.
     using G = RingGeom<H, PF>;
     constexpr int R = G::R, LOOK = G::LOOK;
 #if FDW_ABL_BITS & 32
@@ -104,6 +108,8 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
         return f4_load(a.p + (size_t)row * pitch, hoff);
     };
     auto load_plain = [&](const float* base, int row) -> f4 { return f4_load_stream(base + (size_t)row * pitch, voff); };
+    auto load_f = [&](int row) -> f4 { return f4_load(a.psrc + (size_t)min(max(row, 0), rowmax) * pitch, voff); };
+    auto load_fhalo = [&](int row) -> f4 { return f4_load(a.psrc + (size_t)row * pitch, hoff); };
 
     // ---- prologue: ring rows xa-H .. xa-H+R-1; pointwise rows xa .. xa+PF-1 --------------------
     // Issue order matters: the loop-header s_waitcnt is the stricter of (prologue state, end-of-turn
@@ -111,15 +117,20 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
     // ("virtual steps" -LOOK..-1) makes the two states agree, so no turn starts with a pipeline drain.
     f4 ring[R];
     f4 qhal[PF], qpp[PF], qv2[PF], qps[PF], qim[PF];
+    f4 fring[BACK ? R : 1], fqhal[BACK ? PF : 1], fqpp[BACK ? PF : 1];      // the source field's ring and pointwise queues
     constexpr int NV = LOOK > PF ? LOOK : PF;
     static_for<2 * H>([&](auto K) {
         constexpr int k = decltype(K)::value;
         ring[k] = load_p(xa - H + k);
+        if constexpr (BACK) fring[k] = load_f(xa - H + k);
         __builtin_amdgcn_sched_barrier(0);
     });
     static_for<NV>([&](auto JJ) {
         constexpr int j = decltype(JJ)::value - NV;   // virtual step -NV .. -1
-        if constexpr (j >= -LOOK) ring[j + 2 * H + LOOK] = load_p(xa + j + H + LOOK);
+        if constexpr (j >= -LOOK) {
+            ring[j + 2 * H + LOOK] = load_p(xa + j + H + LOOK);
+            if constexpr (BACK) fring[j + 2 * H + LOOK] = load_f(xa + j + H + LOOK);
+        }
         if constexpr (j >= -PF) {
             constexpr int m = j + PF;
             const int row = min(xa + m, xe - 1);
@@ -129,8 +140,12 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
                 qv2[m] = load_plain(a.v2, row);
             }
             if constexpr (IMG) {
-                qps[m] = load_plain(a.psrc, row);
+                if constexpr (!BACK) qps[m] = load_plain(a.psrc, row);
                 qim[m] = load_plain(a.img, row);
+            }
+            if constexpr (BACK) {
+                fqhal[m] = load_fhalo(row);
+                fqpp[m] = load_plain(a.fpp, row);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -238,11 +253,37 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
                     }
                 }
             }
+            f4 fres;
+            if constexpr (BACK) {
+                // ---- the source field's own step on the same row: kernel_lap + kernel_time, no damping, no injection (R:317-318) ----
+                const f4 fc = fring[(U + H) % R];
+                const f4 fhal = fqhal[Q];
+                f4 flft, frgt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float up = __shfl_up(fc.v[e], 1, 64), dn = __shfl_down(fc.v[e], 1, 64);
+                    flft.v[e] = lane_first ? fhal.v[e] : up;
+                    frgt.v[e] = lane_last ? fhal.v[e] : dn;
+                }
+                const ZPairs fzp = zpairs(flft, fc, frgt);
+                static_for<2>([&](auto PP) {
+                    constexpr int P = decltype(PP)::value;
+                    v2f lap2 = laplacian_pair<H, P>(fzp, [&](auto IO) { return f4_pair(fring[(U + decltype(IO)::value) % R], P); }, cpk);
+                    if (zedge || xedge) lap2 = v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
+                    const v2f prod2 = (f4_pair(qv2[Q], P) * a.dt2) * lap2;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int e = 2 * P + q;
+                        const float upd = leapfrog_prod(fc.v[e], fqpp[Q].v[e], q ? prod2.y : prod2.x);
+                        fres.v[e] = zedge ? (mupd[e] ? upd : fqpp[Q].v[e]) : upd;
+                    }
+                });
+            }
             if constexpr (IMG) {
                 // kernel_img (R:133-144) correlates with the NEW receiver field; the sibling's rtm_main stores the CURRENT one
                 // (rwf[it] = P, rtm_main.cpp:211-215), an interior point of which carries damping factors of exactly 1.0f
 #pragma unroll
-                for (int e = 0; e < 4; ++e) imr.v[e] = qim[Q].v[e] + qps[Q].v[e] * (DD ? c.v[e] : res.v[e]);
+                for (int e = 0; e < 4; ++e) imr.v[e] = qim[Q].v[e] + (BACK ? fres.v[e] : qps[Q].v[e]) * (DD ? c.v[e] : res.v[e]);
             }
 #if FDW_ABL_BITS & (4 | 32)
             if (res.v[0] == 123.456f)
@@ -250,9 +291,11 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
             if (!partial) {
                 f4_store(a.pp + (size_t)r * pitch, voff, res);
                 if constexpr (IMG) f4_store(a.img + (size_t)r * pitch, voff, imr);
+                if constexpr (BACK) f4_store(a.fpp + (size_t)r * pitch, voff, fres);
             } else if (act) {
                 f4_store(a.pp + (size_t)r * pitch, voff, res);
                 if constexpr (IMG) f4_store(a.img + (size_t)r * pitch, voff, imr);
+                if constexpr (BACK) f4_store(a.fpp + (size_t)r * pitch, voff, fres);
             }
 
             // ---- refill the slots this row just freed (look-ahead loads) ----------------------
@@ -265,10 +308,15 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
                     qv2[Q] = load_plain(a.v2, nr);
                 }
                 if constexpr (IMG) {
-                    qps[Q] = load_plain(a.psrc, nr);
+                    if constexpr (!BACK) qps[Q] = load_plain(a.psrc, nr);
                     qim[Q] = load_plain(a.img, nr);
                 }
+                if constexpr (BACK) {
+                    fqhal[Q] = load_fhalo(nr);
+                    fqpp[Q] = load_plain(a.fpp, nr);
+                }
             }
+            if constexpr (BACK) fring[U] = load_f(r - H + R);
         }
         // keep the look-ahead loads where they were issued: without this the machine scheduler
         // sinks each load to one row before its first use to save registers, which turns the
@@ -285,7 +333,7 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
         static_for<R>([&](auto UU) { row_step(rb, UU, std::true_type{}); });
 }
 
-template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false>
+template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false, bool BACK = false>
 __global__ __launch_bounds__(256) void fdw_step_kernel(const StepArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -307,7 +355,7 @@ __global__ __launch_bounds__(256) void fdw_step_kernel(const StepArgs a)
     const int xa = a.r0 + chunk * a.xchunk;
     const int xe = min(xa + a.xchunk, a.r1);
     if (xa >= xe) return;
-    march<H, TAPER, INJ, IMG, LAPONLY, PF, DD>(a, lane, zs, xa, xe);
+    march<H, TAPER, INJ, IMG, LAPONLY, PF, DD, BACK>(a, lane, zs, xa, xe);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -423,6 +471,7 @@ static hipError_t launch_fast_hp(const StepArgs& a, int mode, hipStream_t s)
     case FDW_MODE_MOD:   hipLaunchKernelGGL((fdw_step_kernel<H, true, 3, false, false, PF, true>), grid, block, 0, s, a); break;
     case FDW_MODE_DD_FWD:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 1, false, false, PF, true>), grid, block, 0, s, a); break;
     case FDW_MODE_DD_RECV: hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, PF, true>), grid, block, 0, s, a); break;
+    case FDW_MODE_BACK:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, PF, false, true>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -833,3 +833,24 @@ def test_slabforward_with_asynchronous_streams_on_one_gpu(world, ksteps, pipe):
     own = lambda fw, f: fw.owned(f)[:, :nze]
     assert torch.equal(torch.cat([own(fw, fw.d_pp) for fw in fws]), rb[ipp][:, :nze]), "newest field differs from the single-domain run"
     assert torch.equal(torch.cat([own(fw, fw.d_p) for fw in fws]), rb[ip][:, :nze]), "older field differs from the single-domain run"
+
+
+@pytest.mark.parametrize("order", [8, 4])
+def test_fused_backward_iteration_equals_two_launches(order, monkeypatch):
+    """Backward iterations run as ONE pass (source-field step + receiver step + imaging, FDW_MODE_BACK) on grids below the two-step
+    threshold; the two-launch form (FDW_NO_FUSED_BACK=1) and the oracle give the same image and the same reconstructed state, bit for bit."""
+    d = make_deck(140, 610, 14, 18, 23, seed=17, order=order, compat=True)
+    nx, nz = d["nxe"] - 2 * d["nxb"], d["nze"] - 2 * d["nzb"]
+    srce = O.ricker_wavelet(d["nt"], d["dt"], 30.0)
+    d_obs = np.random.default_rng(8).standard_normal((nx, d["nt"])).astype(np.float32)
+    orc = mko(d)
+    oP, oPP = orc.forward(d["v2"], d["sx"], d["sz"], srce)
+    im0 = np.random.default_rng(9).standard_normal((nx, nz)).astype(np.float32)
+    fused = mk(d)
+    monkeypatch.setenv("FDW_NO_FUSED_BACK", "1")
+    split = mk(d)
+    monkeypatch.delenv("FDW_NO_FUSED_BACK")
+    for n in (d["nt"], 2, 3, 8):
+        want = orc.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n)
+        assert_bit_equal(fused.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n), want, f"fused backward, {n} iterations")
+        assert_bit_equal(split.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n), want, f"two-launch backward, {n} iterations")
