@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import parallel_finite_difference_computation_amd as F
-n, nb = 8192, 64
+n, nb = (int(sys.argv[1]) if len(sys.argv) > 1 else 8192), 64
 nt = 400
 ctx = F.FDWave(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 1e-3, compat=False)
 rng = np.random.default_rng(0)
