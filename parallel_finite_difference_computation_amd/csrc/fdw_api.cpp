@@ -364,6 +364,7 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
     a.upd_z1 = c->upd_z1;
     a.ztap = c->ztap; a.tz_x1 = c->tz_x1; a.xt_lo = c->xt_lo; a.xt_hi = c->xt_hi;
     a.pp_twice = pp_twice ? 1 : 0;
+    a.img_z1 = c->prm.nzb + std::min(c->nz, c->zlim);      // kernel_img: interior columns j < zlim && j < nz (R:133-144)
     a.inj_x = -1; a.inj_z = inj_z; a.inj_n = 0;
     if (mode == FDW_MODE_DD_FWD || mode == FDW_MODE_DD_RECV) { a.dx2inv = c->dx2inv; a.dz2inv = c->dz2inv; }
     if ((mode == FDW_MODE_FWD || mode == FDW_MODE_DD_FWD) && d_inj && inj_x_global >= 0) {
@@ -413,6 +414,15 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
         e = launch_step_generic(a, c->h, mode, s);
     }
     if (e != hipSuccess) return fail(FDW_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    if ((mode == FDW_MODE_RECV || mode == FDW_MODE_BACK) && r1 > c->upd_x1) {
+        // receiver rows beyond the time-stepped rows (narrow x border + truncated extents): the reference still injects and images them
+        const int s0 = std::max(a.inj_x, c->upd_x1), s1 = std::min(a.inj_x + a.inj_n, std::min(r1, c->nxl));
+        if (s1 > s0) {
+            e = launch_static_rows(d_pp, mode == FDW_MODE_BACK ? d_fpp : d_psrc, d_img, a.inj + (s0 - a.inj_x), c->pitch, s0, s1 - s0, inj_z,
+                                   c->prm.nzb, a.img_z1, s);
+            if (e != hipSuccess) return fail(FDW_EHIP, "static-row launch failed: %s", hipGetErrorString(e));
+        }
+    }
     return FDW_OK;
 }
 
@@ -485,6 +495,7 @@ static int step2_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
     a.upd_x1 = c->upd_x1; a.upd_z1 = c->upd_z1;
     a.ztap = c->ztap; a.tz_x1 = c->tz_x1; a.xt_lo = c->xt_lo; a.xt_hi = c->xt_hi;
     a.pp_twice = pp_twice ? 1 : 0;
+    a.img_z1 = c->prm.nzb + std::min(c->nz, c->zlim);
     a.inj_x = -1000000; a.inj_z = inj_z; a.inj_n = 0;
     if (mode == FDW_MODE_FWD && d_inj && inj_x_global >= 0) {
         if (inj_z < 0 || inj_z >= c->prm.nze || inj_x_global >= c->prm.nxe) return fail(FDW_EINVAL, "step2: source (%d,%d) outside the grid", inj_x_global, inj_z);
@@ -526,6 +537,16 @@ static int step2_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
         const size_t off = (size_t)c->upd_x1 * c->pitch, n = (size_t)(c->nxl - c->upd_x1) * c->pitch * sizeof(float);
         HIP_TRY(hipMemcpyAsync(d_out1 + off, d_pp + off, n, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(d_out2 + off, d_p + off, n, hipMemcpyDeviceToDevice, s));
+        if (mode == FDW_MODE_RECV) {
+            // receiver rows among them: iteration it injects into (and images) what is now out1, iteration it+1 what is now out2
+            const int s0 = std::max(a.inj_x, c->upd_x1), s1 = std::min(a.inj_x + a.inj_n, c->nxl);
+            if (s1 > s0) {
+                hipError_t e2 = launch_static_rows(d_out1, ex.psrc_a, ex.img, a.inj + (s0 - a.inj_x), c->pitch, s0, s1 - s0, inj_z, c->prm.nzb, a.img_z1, s);
+                if (e2 == hipSuccess)
+                    e2 = launch_static_rows(d_out2, ex.psrc_b, ex.img, a.inj2 + (s0 - a.inj_x), c->pitch, s0, s1 - s0, inj_z, c->prm.nzb, a.img_z1, s);
+                if (e2 != hipSuccess) return fail(FDW_EHIP, "static-row launch failed: %s", hipGetErrorString(e2));
+            }
+        }
     }
     return FDW_OK;
 }

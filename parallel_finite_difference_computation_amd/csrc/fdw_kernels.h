@@ -25,6 +25,7 @@ struct StepArgs {
     const float* v2;       // [nxl][pitch] squared velocity
     const float* psrc;     // IMG: source wavefield to correlate with; BACK: F_{k-1}, the newer source field (read only)
     float* fpp;            // BACK: F_{k-2}, overwritten with the reconstructed F_k
+    int img_z1;            // IMG: columns >= img_z1 lie outside kernel_img's launch extent (R:133-144) and keep their image value
     float* img;            // IMG: image accumulator on the extended grid
     const float* taperz;   // [ztap] z damping factors
     const float* txfac;    // [nxl] per-row x damping factor (1.0f where none applies)
@@ -64,6 +65,7 @@ struct Step2Args {
     const float* psrc_a;   // RECV: source wavefield of iteration it   (imaged against u^{n+1})
     const float* psrc_b;   // RECV: source wavefield of iteration it+1 (imaged against u^{n+2})
     float* img;            // RECV: image accumulator on the extended grid (in place, owned cells only)
+    int img_z1;            // RECV: columns >= img_z1 lie outside kernel_img's launch extent and keep their image value
     int pitch, nxl;
     int r0, r1;            // rows whose u^{n+1}, u^{n+2} this launch produces
     int r0b, r1b, chunks_a; // pipeline kernel only: optional second row range (chunks >= chunks_a walk [r0b, r1b))
@@ -94,6 +96,9 @@ hipError_t launch_step_generic(const StepArgs& a, int half_order, int mode, hipS
 hipError_t launch_taper_finalize(float* f, const float* taperz, const float* txfac, int pitch, int nxl, int ztap,
                                  int tz_x1, hipStream_t s);
 hipError_t launch_selftest(const float* src, float* out, hipStream_t s);
+// receiver rows the reference injects and images but never time-steps (truncated launch extents with a narrow x border): see fdw_static_rows_kernel
+hipError_t launch_static_rows(float* pp, const float* psrc, float* img, const float* samples, int pitch, int row0, int nrows, int gz,
+                              int img_z0, int img_z1, hipStream_t s);
 hipError_t launch_image_laplacian(const float* d_img, float* d_out, int nx, int nz, float dx, float dz, hipStream_t s);
 
 }  // namespace fdw

@@ -284,6 +284,10 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
                 // (rwf[it] = P, rtm_main.cpp:211-215), an interior point of which carries damping factors of exactly 1.0f
 #pragma unroll
                 for (int e = 0; e < 4; ++e) imr.v[e] = qim[Q].v[e] + (BACK ? fres.v[e] : qps[Q].v[e]) * (DD ? c.v[e] : res.v[e]);
+                if (zedge) {      // kernel_img's launch covers interior columns j < zlim only (R:133-144)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) imr.v[e] = (z0 + e < a.img_z1) ? imr.v[e] : qim[Q].v[e];
+                }
             }
 #if FDW_ABL_BITS & (4 | 32)
             if (res.v[0] == 123.456f)
@@ -445,6 +449,24 @@ __global__ __launch_bounds__(256) void fdw_image_lap_kernel(const float* img, fl
     out[k] = r;
 }
 
+// Receiver rows the reference injects (kernel_sism, R:124-131) and images (kernel_img, R:133-144) although its truncated launch
+// extents never time-step them: rows [xlim, nxb + min(nx, xlim)), which exist only when the x border is narrower than nxe - xlim
+// (decks with nxb < 7).  Their field values are static apart from this injection, but the neighbouring time-stepped row reads them.
+// One thread per cell of those rows: pp(row, gz) += sample; img(row, z) += psrc(row, z) * pp(row, z) for the imaged columns.
+__global__ __launch_bounds__(256) void fdw_static_rows_kernel(float* pp, const float* psrc, float* img, const float* samples, int pitch, int row0,
+                                                              int gz, int img_z0, int img_z1)
+{
+    const int z = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (z >= pitch) return;
+    const size_t k = (size_t)(row0 + i) * pitch + z;
+    float v = pp[k];
+    if (z == gz) {
+        v = v + samples[i];
+        pp[k] = v;
+    }
+    if (z >= img_z0 && z < img_z1) img[k] = img[k] + psrc[k] * v;
+}
+
 __global__ void fdw_selftest_kernel(const float* src, float* out)
 {
     const int t = threadIdx.x;
@@ -518,6 +540,14 @@ hipError_t launch_taper_finalize(float* f, const float* taperz, const float* txf
 hipError_t launch_image_laplacian(const float* d_img, float* d_out, int nx, int nz, float dx, float dz, hipStream_t s)
 {
     hipLaunchKernelGGL(fdw_image_lap_kernel, dim3((nz + 255) / 256, nx), dim3(256), 0, s, d_img, d_out, nx, nz, dx, dz);
+    return hipGetLastError();
+}
+
+hipError_t launch_static_rows(float* pp, const float* psrc, float* img, const float* samples, int pitch, int row0, int nrows, int gz,
+                              int img_z0, int img_z1, hipStream_t s)
+{
+    if (nrows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fdw_static_rows_kernel, dim3((pitch + 255) / 256, nrows), dim3(256), 0, s, pp, psrc, img, samples, pitch, row0, gz, img_z0, img_z1);
     return hipGetLastError();
 }
 

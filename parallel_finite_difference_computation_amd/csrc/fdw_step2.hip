@@ -218,6 +218,7 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
                     for (int e = 0; e < 4; ++e) {
                         im.v[e] = im.v[e] + qsa[Q].v[e] * c2.v[e];
                         im.v[e] = im.v[e] + qsb[Q].v[e] * u2.v[e];
+                        im.v[e] = (z0 + e < a.img_z1) ? im.v[e] : qim[Q].v[e];      // kernel_img's launch covers interior columns j < zlim only
                     }
                     f4_store_rsrc(a.img + rowoff(r), row_bytes, soff2, im);
                 }

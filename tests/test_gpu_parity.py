@@ -854,3 +854,53 @@ def test_fused_backward_iteration_equals_two_launches(order, monkeypatch):
         want = orc.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n)
         assert_bit_equal(fused.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n), want, f"fused backward, {n} iterations")
         assert_bit_equal(split.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n), want, f"two-launch backward, {n} iterations")
+
+
+def test_random_decks_property():
+    """Property test (hypothesis): for randomly drawn small decks -- any even order up to 10, ragged extents, borders from 0 up, truncated or
+    full launch extents, the source anywhere the reference can time-step it, every forward kernel -- fdw_shot's fields and image equal the
+    oracle's bit for bit."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+
+    @st.composite
+    def decks(draw):
+        order = draw(st.sampled_from([2, 4, 6, 8, 8, 8, 10]))
+        h = order // 2
+        nxb = draw(st.integers(0, 20))
+        nzb = draw(st.integers(0, 24))
+        nx = draw(st.integers(max(order + 2, 9), 90))
+        nz = draw(st.integers(max(order + 2, 9), 420))
+        compat = draw(st.booleans())
+        nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+        xlim = 8 * (nxe // 8) if compat else nxe
+        zlim = 8 * (nze // 8) if compat else nze
+        sx = draw(st.integers(nxb, max(nxb, min(nxb + nx - 1, xlim - 1))))
+        sz = draw(st.integers(max(nzb, h), max(max(nzb, h), min(nzb + nz - 1, zlim - 1))))
+        gz = draw(st.integers(nzb, nzb + nz - 1))
+        nt = draw(st.integers(2, 9))
+        mode = draw(st.sampled_from([-1, 1, 4])) if order == 8 else 0
+        fac = draw(st.sampled_from([0.3, 0.75, 1.0]))
+        return dict(order=order, nxe=nxe, nze=nze, nxb=nxb, nzb=nzb, nt=nt, compat=compat, sx=sx, sz=sz, gz=gz, mode=mode, fac=fac,
+                    seed=draw(st.integers(0, 10**6)))
+
+    seen = []
+
+    @settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(decks())
+    def check(c):
+        seen.append((c["order"], c["mode"], c["compat"]))
+        d = make_deck(c["nxe"], c["nze"], c["nxb"], c["nzb"], c["nt"], seed=c["seed"], order=c["order"], compat=c["compat"], fac=c["fac"])
+        nx, nz = c["nxe"] - 2 * c["nxb"], c["nze"] - 2 * c["nzb"]
+        srce = (O.ricker_wavelet(c["nt"], d["dt"], 30.0) + 0.5).astype(np.float32)
+        d_obs = np.random.default_rng(c["seed"]).standard_normal((nx, c["nt"])).astype(np.float32)
+        ctx, orc = mk(d), mko(d)
+        ctx.set_tuning(two_step=c["mode"])
+        img, P, PP = ctx.shot(d["v2"], c["sx"], c["sz"], c["gz"], srce, d_obs, want_fields=True)
+        oP, oPP = orc.forward(d["v2"], c["sx"], c["sz"], srce)
+        oimg = orc.back(d["v2"], oP, oPP, d_obs, c["gz"])
+        assert_bit_equal(P, oP, f"P {c}")
+        assert_bit_equal(PP, oPP, f"PP {c}")
+        assert_bit_equal(img, oimg, f"image {c}")
+
+    check()
+    assert len(seen) >= 100 and {m for (o, m, _) in seen if o == 8} == {-1, 1, 4} and {o for (o, _, _) in seen} == {2, 4, 6, 8, 10}, len(seen)
