@@ -1,6 +1,8 @@
 """GPU: the HIP path (libfdwave.so through its C ABI) against the CPU oracle and the reference's
 known answers.  fp32 results are expected BIT-EXACT against the oracle (same operations in the same
 order, no FMA contraction); against the real-hardware golden the bar is 1e-5 max-norm-relative."""
+import os
+
 import numpy as np
 import pytest
 
@@ -885,7 +887,8 @@ def test_random_decks_property():
 
     seen = []
 
-    @settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @settings(max_examples=int(os.environ.get("FDW_PROPERTY_EXAMPLES", "150")), deadline=None, suppress_health_check=list(HealthCheck),
+              derandomize="FDW_PROPERTY_RANDOM" not in os.environ, database=None)
     @given(decks())
     def check(c):
         seen.append((c["order"], c["mode"], c["compat"]))
@@ -904,3 +907,53 @@ def test_random_decks_property():
 
     check()
     assert len(seen) >= 100 and {m for (o, m, _) in seen if o == 8} == {-1, 1, 4} and {o for (o, _, _) in seen} == {2, 4, 6, 8, 10}, len(seen)
+
+
+def test_random_modelling_and_stored_rtm_decks_property():
+    """Property test over the two widened dialects: randomly drawn decks (orders 2..8, ragged extents, borders from 0 up, unequal
+    spacings, source and receiver depth anywhere in the interior, one-step kernel or the wave pipeline for the modelling loop) --
+    fdw_model_shot's gather and fdw_rtm_stored_shot's image equal the oracle's bit for bit."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+
+    @st.composite
+    def decks(draw):
+        order = draw(st.sampled_from([2, 4, 6, 8, 8, 8]))
+        nxb = draw(st.integers(0, 18))
+        nzb = draw(st.integers(0, min(22, 2 * nxb)))           # the stored-field RTM offsets its receivers by nzb rows: must stay in the grid
+        nx = draw(st.integers(max(order + 2, 9), 80))
+        nz = draw(st.integers(max(order + 2, 9), 380))
+        return dict(order=order, nx=nx, nz=nz, nxb=nxb, nzb=nzb, nt=draw(st.integers(1, 11)),
+                    dx=draw(st.sampled_from([8.0, 10.0, 12.5])), dz=draw(st.sampled_from([8.0, 10.0, 12.5])),
+                    fac=draw(st.sampled_from([0.02, 0.05, 0.3])), pipe=draw(st.booleans()), xchunk=draw(st.sampled_from([0, 5, 11])),
+                    sx=nxb + draw(st.integers(0, nx - 1)), sz=nzb + draw(st.integers(0, nz - 1)), gz=nzb + draw(st.integers(0, nz - 1)),
+                    shot=draw(st.integers(0, 1)), seed=draw(st.integers(0, 10**6)))
+
+    seen = []
+
+    @settings(max_examples=int(os.environ.get("FDW_PROPERTY_EXAMPLES", "100")), deadline=None, suppress_health_check=list(HealthCheck),
+              derandomize="FDW_PROPERTY_RANDOM" not in os.environ, database=None)
+    @given(decks())
+    def check(c):
+        seen.append((c["order"], c["pipe"]))
+        nx, nz, nxb, nzb, nt = c["nx"], c["nz"], c["nxb"], c["nzb"], c["nt"]
+        nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+        rng = np.random.default_rng(c["seed"])
+        vp = (1500 + 2500 * rng.random((nx, nz))).astype(np.float32)
+        v2 = np.zeros((nxe, nze), np.float32)
+        v2[nxb:nxb + nx, nzb:nzb + nz] = vp * vp
+        v2 = F.mod_extendvel(v2, nx, nz, nxb, nzb)
+        srce = (F.mod_ricker_wavelet(nt, 0.001, 40.0) + 0.1 * rng.standard_normal(nt)).astype(np.float32)
+        ctx = F.FDWave(c["order"], nxe, nze, nxb, nzb, nt, c["fac"], c["dx"], c["dz"], 0.001, dialect=1)
+        if c["order"] == 8 and c["pipe"]:
+            ctx.set_tuning(xchunk=c["xchunk"], two_step=4)
+        got = ctx.model_shot(v2, c["sx"], c["sz"], c["gz"], srce)
+        want = O.mod_shot(c["order"], nx, nz, nxb, nzb, c["dx"], c["dz"], 0.001, c["fac"], v2, c["sx"], c["sz"], c["gz"], srce)
+        assert_bit_equal(got, want, f"gather {c}")
+        dobs = rng.standard_normal((2, nx, nt)).astype(np.float32)
+        ctx2 = F.FDWave(c["order"], nxe, nze, nxb, nzb, nt, c["fac"], c["dx"], c["dz"], 0.001, dialect=2)
+        gimg = ctx2.rtm_stored_shot(v2, c["sx"], c["sz"], c["gz"], srce, dobs, shot=c["shot"])
+        wimg = O.rtm_stored_shot(c["order"], nx, nz, nxb, nzb, c["dx"], c["dz"], 0.001, c["fac"], v2, c["sx"], c["sz"], c["gz"], srce, dobs, shot=c["shot"])
+        assert_bit_equal(gimg, wimg, f"image {c}")
+
+    check()
+    assert {o for o, _ in seen} == {2, 4, 6, 8} and {p for _, p in seen} == {True, False}
