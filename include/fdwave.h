@@ -198,6 +198,25 @@ int fdw_image_laplacian(int device, const float *img, int nx, int nz, float dx, 
 int fdw_upload_field(fdw_ctx *ctx, float *d_dst, const float *h_src);
 int fdw_download_field(fdw_ctx *ctx, float *h_dst, const float *d_src);
 
+/* ---- random-border model generated on the device ---------------------
+ * The reference rebuilds its extended velocity model on the host for every shot (extendvel_linear, F:336-394, called at
+ * R:486; vel2 = vpe * vpe at R:488-494) and uploads it (R:205).  Here the interior model is uploaded once and each
+ * shot's border is generated in HBM from the same unseeded glibc rand() stream, addressed by position: shot s of a
+ * fresh process consumes draws [s T, (s+1) T), T = fdw_border_draws(...).  Cells the reference's loops never write
+ * (bottom corners when nxb > nzb) are zero, as in the reference's calloc'ed array.
+ * fdw_border_draws          rand() calls one extendvel_linear consumes: nx nzb + 2 nz nxb + 2 nzb (nzb + 1)
+ * fdw_model_resident        uploads the interior velocity vp[nx][nz] (not squared); RTM dialect, full-grid context
+ * fdw_dev_extendvel_linear  fills the context's resident vel2 (and vel_out[nxe][nze] on the host if not NULL) from
+ *                           draws [draw_offset, draw_offset + T) of the seed-1 stream
+ * fdw_shot_resident         fdw_shot (R:496-520) on the resident vel2; FDW_ESTATE if a host model was uploaded since
+ * fdw_rand_stream           out[i] = draw number draw_offset + i of that stream, produced by the device generator (tests)
+ */
+long long fdw_border_draws(int nx, int nz, int nxb, int nzb);
+int fdw_model_resident(fdw_ctx *ctx, const float *vp);
+int fdw_dev_extendvel_linear(fdw_ctx *ctx, unsigned long long draw_offset, float *vel_out);
+int fdw_shot_resident(fdw_ctx *ctx, int sx, int sz, int gz, const float *srce, const float *d_obs, float *imloc, float *P, float *PP);
+int fdw_rand_stream(fdw_ctx *ctx, unsigned long long draw_offset, long long n, int *out);
+
 /* ---- tuning / introspection --------------------------------------------------------------------
  * fdw_set_tuning  xchunk = rows marched per wave (0 = auto), wz = waves of a block laid along z
  *                 (1,2,4; 0 = auto), use_generic = force the generic-order kernel (tests),

@@ -54,6 +54,11 @@ SIGNATURES = [
     ("fdw_model_shot", C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p]),
     ("fdw_image_laplacian", C.c_int, [C.c_int, f32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p]),
     ("fdw_rtm_stored_shot", C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_size_t, C.c_int, f32p]),
+    ("fdw_border_draws", C.c_longlong, [C.c_int] * 4),
+    ("fdw_model_resident", C.c_int, [vp, f32p]),
+    ("fdw_dev_extendvel_linear", C.c_int, [vp, C.c_ulonglong, vp]),
+    ("fdw_shot_resident", C.c_int, [vp, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, vp, vp]),
+    ("fdw_rand_stream", C.c_int, [vp, C.c_ulonglong, C.c_longlong, vp]),
     ("fdw_dev_model_steps", C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
     ("fdw_mod_extendvel", None, [C.c_int] * 4 + [f32p]),
     ("fdw_mod_ricker_wavelet", None, [C.c_int, C.c_float, C.c_float, f32p]),

@@ -183,6 +183,38 @@ class FDWave:
                              P.ctypes.data if want_fields else None, PP.ctypes.data if want_fields else None))
         return (imloc, P, PP) if want_fields else imloc
 
+    # ---- random-border model generated on the device ----
+    def border_draws(self):
+        """rand() calls one extendvel_linear (functions.c:336-394) consumes on this geometry."""
+        return int(lib().fdw_border_draws(self.nx, self.nz, self.nxb, self.nzb))
+
+    def model_resident(self, vp):
+        """Upload the interior velocity model vp[nx][nz] (not squared) once; the per-shot borders are then drawn on the device."""
+        check(lib().fdw_model_resident(self._h, _f32(vp, (self.nx, self.nz))))
+
+    def dev_extendvel_linear(self, draw_offset, want_vel=False):
+        """extendvel_linear + vel2 = vpe * vpe (fd-code.cu:486-494) in HBM, from draws [draw_offset, draw_offset + border_draws()) of the
+        unseeded glibc rand() stream.  want_vel: also return the extended model [nxe][nze]."""
+        vel = np.zeros((self.nxe, self.nze), np.float32) if want_vel else None
+        check(lib().fdw_dev_extendvel_linear(self._h, int(draw_offset), vel.ctypes.data if want_vel else None))
+        return vel
+
+    def shot_resident(self, sx, sz, gz, srce, d_obs, imloc=None, want_fields=False):
+        """shot() on the squared model dev_extendvel_linear left in HBM."""
+        shape = (self.nxe, self.nze)
+        imloc = np.zeros((self.nx, self.nz), np.float32) if imloc is None else np.array(imloc, np.float32, order="C")
+        P = np.zeros(shape, np.float32) if want_fields else None
+        PP = np.zeros(shape, np.float32) if want_fields else None
+        check(lib().fdw_shot_resident(self._h, sx, sz, gz, _f32(srce, (self.nt,)), _f32(d_obs, (self.nx, self.nt)), imloc,
+                                      P.ctypes.data if want_fields else None, PP.ctypes.data if want_fields else None))
+        return (imloc, P, PP) if want_fields else imloc
+
+    def rand_stream(self, draw_offset, n):
+        """Draws [draw_offset, draw_offset + n) of the unseeded glibc rand() stream as the device generator produces them."""
+        out = np.zeros(n, np.int32)
+        check(lib().fdw_rand_stream(self._h, int(draw_offset), n, out.ctypes.data))
+        return out
+
     def model_shot(self, vel2, sx, sz, gz, srce):
         """One shot of mod_main's loop (dpct_gpu_rtm_domain_division/src/mod_main.cpp:140-174): the gather data[nx][nt]."""
         srce = _f32(srce)

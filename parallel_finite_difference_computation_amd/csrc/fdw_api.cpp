@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -73,6 +74,12 @@ struct fdw_ctx {
     // tuning
     int xchunk = 0, wz = 0, use_generic = 0, prefetch = 0, force_edge = 0, xchunk2 = 0;
     int tb = 0;   // two-steps-per-pass kernel: 0 auto (large grids), 1 always, -1 never
+    // random-border model generated on the device (row f4): interior model, one call's draws, jump tables, the extended model
+    float *d_vp = nullptr, *d_vpe = nullptr;
+    int* d_draws = nullptr;
+    unsigned* d_jump = nullptr;
+    int njump = 0;
+    bool model_resident = false, v2_resident = false;
     int no_fused_back = 0;   // experiments / tests: backward iterations as two launches (source step, receiver step) -- FDW_NO_FUSED_BACK=1
 };
 
@@ -292,7 +299,8 @@ extern "C" void fdw_destroy(fdw_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     float* bufs[] = {c->d_taperz, c->d_txfac, c->d_gcx, c->d_gcz, c->fld[0], c->fld[1], c->fld[2], c->fld[3],
-                     c->fld[4], c->fld[5], c->fld[6], c->fld[7], c->d_v2, c->d_img, c->d_srce, c->d_dobs, c->d_rec};
+                     c->fld[4], c->fld[5], c->fld[6], c->fld[7], c->d_v2, c->d_img, c->d_srce, c->d_dobs, c->d_rec,
+                     c->d_vp, c->d_vpe, (float*)c->d_draws, (float*)c->d_jump};
     for (float* b : bufs)
         if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -734,6 +742,7 @@ extern "C" int fdw_dev_taper_finalize(fdw_ctx* c, float* d_f, void* stream)
 // ------------------------------------------------------------------------------------------------
 static int upload_rows(fdw_ctx* c, float* d_dst, const float* h_src, hipStream_t s)
 {
+    if (d_dst == c->d_v2) c->v2_resident = false;
     HIP_TRY(hipMemcpy2DAsync(d_dst, (size_t)c->pitch * sizeof(float), h_src, (size_t)c->prm.nze * sizeof(float),
                              (size_t)c->prm.nze * sizeof(float), c->nxl, hipMemcpyHostToDevice, s));
     return FDW_OK;
@@ -956,10 +965,10 @@ extern "C" int fdw_back(fdw_ctx* c, const float* v2, const float* snap0, const f
     return FDW_OK;
 }
 
-extern "C" int fdw_shot(fdw_ctx* c, const float* v2, int sx, int sz, int gz, const float* srce, const float* d_obs,
-                        float* imloc, float* P, float* PP)
+// v2 == nullptr: the squared model already resident in c->d_v2 (fdw_dev_extendvel_linear)
+static int shot_impl(fdw_ctx* c, const float* v2, int sx, int sz, int gz, const float* srce, const float* d_obs, float* imloc, float* P, float* PP)
 {
-    if (!c || !v2 || !srce || !d_obs || !imloc) return fail(FDW_EINVAL, "NULL argument");
+    if (!c || !srce || !d_obs || !imloc) return fail(FDW_EINVAL, "NULL argument");
     if (!is_full_grid(c)) return fail(FDW_EINVAL, "fdw_shot needs a full-grid context");
     if (c->nx <= 0 || c->nz <= 0) return fail(FDW_EINVAL, "no interior to image");
     HIP_TRY(hipSetDevice(c->device));
@@ -969,7 +978,7 @@ extern "C" int fdw_shot(fdw_ctx* c, const float* v2, int sx, int sz, int gz, con
     int ip = 0, ipp = 1;
     HIP_TRY(hipMemsetAsync(c->fld[0], 0, field_elems(c) * sizeof(float), c->stream));    // R:496-497
     HIP_TRY(hipMemsetAsync(c->fld[1], 0, field_elems(c) * sizeof(float), c->stream));
-    if ((rc = upload_rows(c, c->d_v2, v2, c->stream)) || (rc = upload_source(c, srce, nt)) || (rc = upload_gather(c, d_obs)) ||
+    if ((v2 && (rc = upload_rows(c, c->d_v2, v2, c->stream))) || (rc = upload_source(c, srce, nt)) || (rc = upload_gather(c, d_obs)) ||
         (rc = image_to_device(c, imloc)))
         return rc;
     if ((rc = forward_loop(c, &ip, &ipp, sx, sz, nt))) return rc;
@@ -986,6 +995,14 @@ extern "C" int fdw_shot(fdw_ctx* c, const float* v2, int sx, int sz, int gz, con
     if ((rc = image_to_host(c, imloc))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return FDW_OK;
+}
+
+extern "C" int fdw_shot(fdw_ctx* c, const float* v2, int sx, int sz, int gz, const float* srce, const float* d_obs,
+                        float* imloc, float* P, float* PP)
+{
+    if (!v2) return fail(FDW_EINVAL, "NULL argument");
+    if (c) c->v2_resident = false;
+    return shot_impl(c, v2, sx, sz, gz, srce, d_obs, imloc, P, PP);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1214,4 +1231,181 @@ extern "C" int fdw_selftest(fdw_ctx* c)
         }
     }
     return FDW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// random-border velocity model generated on the device
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int L = fdw::kRandLag;
+using Mat = std::vector<unsigned>;     // 31 x 31 over Z/2^32, row-major
+
+Mat mat_mul(const Mat& a, const Mat& b)
+{
+    Mat r((size_t)L * L, 0u);
+    for (int i = 0; i < L; i++)
+        for (int k = 0; k < L; k++) {
+            const unsigned aik = a[(size_t)i * L + k];
+            if (!aik) continue;
+            for (int j = 0; j < L; j++) r[(size_t)i * L + j] += aik * b[(size_t)k * L + j];
+        }
+    return r;
+}
+
+struct RandTables {
+    Mat pow2[64];        // M^(2^j): one stream position per application
+    Mat jump31[40];      // M^(31 2^j): one ring turn per application
+    unsigned w0[L];      // window before the first step of a seed-1 generator (before glibc's 310 discarded outputs)
+};
+
+// The window W = (y[K-31] .. y[K-1]) advances by  W' = (w1 .. w30, w0 + w28)  (y[K] = y[K-31] + y[K-3]).
+const RandTables& rand_tables()
+{
+    static RandTables t;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        Mat m((size_t)L * L, 0u);
+        for (int i = 0; i + 1 < L; i++) m[(size_t)i * L + i + 1] = 1;
+        m[(size_t)(L - 1) * L + 0] = 1;
+        m[(size_t)(L - 1) * L + 28] = 1;
+        t.pow2[0] = m;
+        for (int j = 1; j < 64; j++) t.pow2[j] = mat_mul(t.pow2[j - 1], t.pow2[j - 1]);
+        Mat m31 = t.pow2[0];                                  // 31 = 1 + 2 + 4 + 8 + 16
+        for (int j = 1; j < 5; j++) m31 = mat_mul(t.pow2[j], m31);
+        t.jump31[0] = m31;
+        for (int j = 1; j < 40; j++) t.jump31[j] = mat_mul(t.jump31[j - 1], t.jump31[j - 1]);
+        // glibc srandom_r(1): r[0] = seed, r[i] = 16807 r[i-1] mod (2^31 - 1) by Schrage's method; front pointer at r[3], rear at r[0]
+        unsigned r[L];
+        int word = 1;
+        r[0] = 1u;
+        for (int k = 1; k < L; k++) {
+            const long hi = word / 127773, lo = word % 127773;
+            long v = 16807 * lo - 2836 * hi;
+            if (v < 0) v += 2147483647;
+            word = (int)v;
+            r[k] = (unsigned)word;
+        }
+        // step t adds slot t mod 31 into slot (t + 3) mod 31, i.e. y[t] = y[t-31] + y[t-3] with y[s] = r[(s + 34) mod 31] for s in [-31, 0)
+        for (int s = 0; s < L; s++) t.w0[s] = r[(s + 3) % L];
+    });
+    return t;
+}
+
+fdw::RandWindow window_at(unsigned long long k)
+{
+    const RandTables& t = rand_tables();
+    unsigned w[L], v[L];
+    std::memcpy(w, t.w0, sizeof w);
+    for (int j = 0; j < 64; j++)
+        if ((k >> j) & 1) {
+            const Mat& m = t.pow2[j];
+            for (int i = 0; i < L; i++) {
+                unsigned acc = 0;
+                for (int c = 0; c < L; c++) acc += m[(size_t)i * L + c] * w[c];
+                v[i] = acc;
+            }
+            std::memcpy(w, v, sizeof w);
+        }
+    fdw::RandWindow out;
+    std::memcpy(out.w, w, sizeof w);
+    return out;
+}
+
+constexpr unsigned long long kGlibcDiscard = 310;     // outputs srandom_r() throws away
+
+int ensure_rand_tables(fdw_ctx* c, long long ndraws)
+{
+    int need = 1;
+    while (((ndraws + L - 1) / L) >> need) need++;
+    if (need > 40) return fail(FDW_EINVAL, "%lld draws in one call", ndraws);
+    if (c->d_jump && c->njump >= need) return FDW_OK;
+    if (c->d_jump) (void)hipFree(c->d_jump);
+    c->d_jump = nullptr;
+    const RandTables& t = rand_tables();
+    std::vector<unsigned> flat((size_t)need * L * L);
+    for (int j = 0; j < need; j++) std::memcpy(&flat[(size_t)j * L * L], t.jump31[j].data(), (size_t)L * L * sizeof(unsigned));
+    hipError_t e = hipMalloc((void**)&c->d_jump, flat.size() * sizeof(unsigned));
+    if (e != hipSuccess) return fail(FDW_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpy(c->d_jump, flat.data(), flat.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    c->njump = need;
+    return FDW_OK;
+}
+}  // namespace
+
+extern "C" long long fdw_border_draws(int nx, int nz, int nxb, int nzb)
+{
+    if (nx < 0 || nz < 0 || nxb < 0 || nzb < 0) return -1;
+    return (long long)nx * nzb + 2ll * nz * nxb + 2ll * nzb * (nzb + 1);
+}
+
+extern "C" int fdw_rand_stream(fdw_ctx* c, unsigned long long draw_offset, long long n, int* out)
+{
+    if (!c || (!out && n > 0) || n < 0) return fail(FDW_EINVAL, "bad argument");
+    if (n == 0) return FDW_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_rand_tables(c, n);
+    if (rc) return rc;
+    int* d = nullptr;
+    hipError_t e = hipMalloc((void**)&d, (size_t)n * sizeof(int));
+    if (e != hipSuccess) return fail(FDW_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    e = launch_rand_stream(window_at(kGlibcDiscard + draw_offset), c->d_jump, c->njump, n, d, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(FDW_EHIP, "rand_stream: %s", hipGetErrorString(e));
+    return FDW_OK;
+}
+
+extern "C" int fdw_model_resident(fdw_ctx* c, const float* vp)
+{
+    if (!c || !vp) return fail(FDW_EINVAL, "NULL argument");
+    if (c->prm.dialect != FDW_DIALECT_RTM) return fail(FDW_ESTATE, "the random-border model belongs to the RTM dialect");
+    if (!is_full_grid(c)) return fail(FDW_EINVAL, "fdw_model_resident needs a full-grid context");
+    if (c->nx <= 0 || c->nz <= 0) return fail(FDW_EINVAL, "no interior");
+    const int nxb = c->prm.nxb, nzb = c->prm.nzb;
+    if (nxb == 1 || nzb == 1) return fail(FDW_EINVAL, "a border of one cell divides by zero in the reference's ramp (nb - 1)");
+    if (nzb > c->prm.nxe) return fail(FDW_EINVAL, "nzb=%d > nxe=%d: the reference's corner loops leave the array", nzb, c->prm.nxe);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_work_buffers(c, 0, false);
+    if (rc) return rc;
+    const size_t n = (size_t)c->nx * c->nz;
+    if (!c->d_vp) {
+        hipError_t e = hipMalloc((void**)&c->d_vp, n * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_draws, (size_t)std::max<long long>(fdw_border_draws(c->nx, c->nz, nxb, nzb), 1) * sizeof(int));
+        if (e != hipSuccess) return fail(FDW_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    if ((rc = alloc_zero(&c->d_vpe, field_elems(c)))) return rc;
+    if ((rc = ensure_rand_tables(c, std::max<long long>(fdw_border_draws(c->nx, c->nz, nxb, nzb), 1)))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_vp, vp, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->model_resident = true;
+    c->v2_resident = false;
+    return FDW_OK;
+}
+
+extern "C" int fdw_dev_extendvel_linear(fdw_ctx* c, unsigned long long draw_offset, float* vel_out)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    if (!c->model_resident) return fail(FDW_ESTATE, "no resident model: call fdw_model_resident first");
+    HIP_TRY(hipSetDevice(c->device));
+    const long long n = fdw_border_draws(c->nx, c->nz, c->prm.nxb, c->prm.nzb);
+    hipError_t e = launch_rand_stream(window_at(kGlibcDiscard + draw_offset), c->d_jump, c->njump, n, c->d_draws, c->stream);
+    if (e != hipSuccess) return fail(FDW_EHIP, "rand_stream launch failed: %s", hipGetErrorString(e));
+    BorderArgs a{c->d_vp, c->d_draws, c->d_vpe, c->d_v2, c->nx, c->nz, c->prm.nxb, c->prm.nzb, c->pitch};
+    e = launch_extendvel(a, c->stream);
+    if (e != hipSuccess) return fail(FDW_EHIP, "extendvel launch failed: %s", hipGetErrorString(e));
+    c->v2_resident = true;
+    if (vel_out) {
+        int rc = download_rows(c, vel_out, c->d_vpe, c->stream);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return FDW_OK;
+}
+
+extern "C" int fdw_shot_resident(fdw_ctx* c, int sx, int sz, int gz, const float* srce, const float* d_obs, float* imloc, float* P, float* PP)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    if (!c->v2_resident) return fail(FDW_ESTATE, "no resident squared model: call fdw_dev_extendvel_linear first");
+    return shot_impl(c, nullptr, sx, sz, gz, srce, d_obs, imloc, P, PP);
 }

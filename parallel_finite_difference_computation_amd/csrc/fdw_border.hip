@@ -1,0 +1,136 @@
+// Random-border velocity model on the device: extendvel_linear (cuda_reference_RTM/src/functions.c:336-394)
+// and vel2 = vpe * vpe (fd-code.cu:488-494) from an interior model that stays resident in HBM, so a shot uploads nothing but its gather.
+//
+// The reference draws its border from ONE sequential glibc rand() stream, never seeded, consumed in a fixed loop order (fdw_host.c keeps
+// that order for the host array).  Two facts make it a data-parallel job:
+//   * the generator is glibc's TYPE_3 additive feedback  y[t] = y[t-31] + y[t-3]  over 32-bit words, a LINEAR recurrence: the window
+//     W_K = (y[K-31] .. y[K-1]) is  M^K W_0  for one fixed 31x31 matrix M over Z/2^32, so any thread can jump to its own place in the
+//     stream with a few matrix-vector products (tables of M^(31 2^j), built once on the host by repeated squaring) and then run the
+//     recurrence for one ring turn of 31 draws;
+//   * which draw a border cell receives, and whether a later phase of the reference's loops overwrites it, is a closed form of its
+//     coordinates (the phases below), so the fill is one thread per cell with no ordering between cells.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "fdw_kernels.h"
+
+namespace fdw {
+
+namespace {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void unroll(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        unroll<I + 1, N>(f);
+    }
+}
+
+// thread t: draws [31 t, 31 t + 31) of the n asked for, counted from the window `w0` (= the stream position of draw 0)
+__global__ __launch_bounds__(64) void fdw_rand_stream_kernel(RandWindow w0, const unsigned* __restrict__ jump, int njump, long long n, int* __restrict__ out)
+{
+    const long long t = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (t * kRandLag >= n) return;
+    unsigned w[kRandLag];
+    unroll<0, kRandLag>([&](auto s) { w[s] = w0.w[s]; });
+    // jump by 31 t = sum of 31 2^j over the set bits of t; every thread of the launch walks the same tables (scalar loads)
+    for (int j = 0; j < njump; j++) {
+        const unsigned* m = jump + (size_t)j * kRandLag * kRandLag;
+        const bool take = (t >> j) & 1;
+        unsigned v[kRandLag];
+        unroll<0, kRandLag>([&](auto r) {
+            unsigned acc = 0;
+            unroll<0, kRandLag>([&](auto c) { acc += m[r * kRandLag + c] * w[c]; });
+            v[r] = acc;
+        });
+        unroll<0, kRandLag>([&](auto s) { w[s] = take ? v[s] : w[s]; });
+    }
+    // one ring turn: slot s holds y[K-31+s]; y[K+s] = y[K+s-31] + y[K+s-3], and slot (s+28) mod 31 holds y[K+s-3] by then
+    const long long base = t * kRandLag;
+    unroll<0, kRandLag>([&](auto s) {
+        w[s] += w[(s + 28) % kRandLag];
+        if (base + s < n) out[base + s] = (int)(w[s] >> 1);
+    });
+}
+
+__device__ __forceinline__ float ramp_to_floor(float v, int k, int nb)
+{
+    const float floor_v = 300.f;
+    return v - (v - floor_v) * (float)k / (float)(nb - 1);
+}
+__device__ __forceinline__ float draw_near(int r, float v, float centre)
+{
+    const float half = 200.f;
+    const int span = (int)(v + half - (centre - half) + 1.f);
+    return (float)(r % span) + centre - half;
+}
+
+// one thread per cell of the extended grid; `vp` = interior model [nx][nz]; writes vel (may be null) and vel2, both [nxe][pitch]
+__global__ __launch_bounds__(256) void fdw_extendvel_kernel(BorderArgs a)
+{
+    const int z = blockIdx.x * 256 + threadIdx.x;
+    const int x = blockIdx.y;
+    const int nxe = a.nx + 2 * a.nxb, nze = a.nz + 2 * a.nzb;
+    if (z >= nze) return;
+    const int x_first = a.nxb, x_last = a.nxb + a.nx - 1, z_first = a.nzb, z_last = a.nzb + a.nz - 1, x_end = nxe - 1, z_end = nze - 1;
+    auto interior = [&](int i, int j) { return a.vp[(size_t)(i - x_first) * a.nz + (j - z_first)]; };
+    const long long b2 = (long long)a.nx * a.nzb, b4 = b2 + 2ll * a.nz * a.nxb, corner = (long long)a.nzb * (a.nzb + 1);
+    const int bz = z_end - z;                    // depth counted from the bottom edge
+    float v = 0.f;                               // cells no phase writes (bottom corners wider than deep) keep the caller's zero
+    // the reference's phases, latest writer first
+    int side = -1, ca = 0;
+    if (bz < a.nzb) {
+        if (x_end - x < a.nzb) side = 1, ca = x_end - x;          // bottom-right corner triangle pair (done after the left one)
+        else if (x < a.nzb) side = 0, ca = x;
+    }
+    if (side >= 0) {
+        // visit (m, n <= m) writes (n, depth m) with its first draw and (m, depth n) with its second
+        const bool second = ca >= bz;
+        const int m = second ? ca : bz, n = second ? bz : ca;
+        const long long idx = b4 + side * corner + 2 * ((long long)m * (m + 1) / 2 + n) + (second ? 1 : 0);
+        const float edge = interior(side ? x_last : x_first, z_last);
+        v = draw_near(a.draws[idx], edge, ramp_to_floor(edge, a.nxb - 1 - n, a.nzb));
+    } else if (z < z_first && (x < x_first || x > x_last)) {
+        v = interior(x < x_first ? x_first : x_last, z_first);    // top corners: the replicated top of the first / last interior column
+    } else if (x < x_first || x > x_last) {
+        if (z <= z_last) {                                        // left / right borders at interior depths
+            const bool right = x > x_last;
+            const int d = right ? x - x_last - 1 : x_first - 1 - x;
+            const long long idx = b2 + 2 * ((long long)(z - z_first) * a.nxb + d) + (right ? 1 : 0);
+            const float edge = interior(right ? x_last : x_first, z);
+            v = draw_near(a.draws[idx], edge, ramp_to_floor(edge, d, a.nxb));
+        }
+    } else if (z < z_first) {
+        v = interior(x, z_first);                                 // top border: first interior sample replicated
+    } else if (z > z_last) {
+        const int d = z - z_last - 1;                             // bottom border
+        const float edge = interior(x, z_last);
+        v = draw_near(a.draws[(long long)(x - x_first) * a.nzb + d], edge, ramp_to_floor(edge, d, a.nzb));
+    } else {
+        v = interior(x, z);
+    }
+    const size_t o = (size_t)x * a.pitch + z;
+    if (a.vel) a.vel[o] = v;
+    a.vel2[o] = v * v;
+}
+
+}  // namespace
+
+hipError_t launch_rand_stream(const RandWindow& w0, const unsigned* d_jump, int njump, long long n, int* d_out, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const long long threads = (n + kRandLag - 1) / kRandLag;
+    hipLaunchKernelGGL(fdw_rand_stream_kernel, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, s, w0, d_jump, njump, n, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_extendvel(const BorderArgs& a, hipStream_t s)
+{
+    const int nxe = a.nx + 2 * a.nxb, nze = a.nz + 2 * a.nzb;
+    hipLaunchKernelGGL(fdw_extendvel_kernel, dim3((nze + 255) / 256, nxe), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace fdw

@@ -101,4 +101,20 @@ hipError_t launch_static_rows(float* pp, const float* psrc, float* img, const fl
                               int img_z0, int img_z1, hipStream_t s);
 hipError_t launch_image_laplacian(const float* d_img, float* d_out, int nx, int nz, float dx, float dz, hipStream_t s);
 
+// ---- random-border velocity model on the device (fdw_border.hip) ----
+constexpr int kRandLag = 31;          // glibc TYPE_3: y[t] = y[t-31] + y[t-3]
+struct RandWindow {                   // (y[K-31] .. y[K-1]) for a stream position K
+    unsigned w[kRandLag];
+};
+struct BorderArgs {
+    const float* vp;                  // interior model [nx][nz]
+    const int* draws;                 // the rand() values one extendvel_linear call consumes, in its order
+    float* vel;                       // extended model [nxe][pitch] (may be null)
+    float* vel2;                      // its square [nxe][pitch]
+    int nx, nz, nxb, nzb, pitch;
+};
+// d_jump: njump matrices M^(31 2^j), row-major 31x31 each; d_out[i] = draw number i counted from window w0
+hipError_t launch_rand_stream(const RandWindow& w0, const unsigned* d_jump, int njump, long long n, int* d_out, hipStream_t s);
+hipError_t launch_extendvel(const BorderArgs& a, hipStream_t s);
+
 }  // namespace fdw

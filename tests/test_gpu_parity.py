@@ -957,3 +957,77 @@ def test_random_modelling_and_stored_rtm_decks_property():
 
     check()
     assert {o for o, _ in seen} == {2, 4, 6, 8} and {p for _, p in seen} == {True, False}
+
+
+# ---- random-border velocity model generated on the device -----------------------------------------------
+def test_device_rand_stream_is_glibc_rand():
+    """The device generator (jump-ahead through the additive-feedback recurrence) against libc's own rand() after srand(1): the first draws,
+    a window deep in the stream, and lengths that are not a multiple of the 31-draw ring turn."""
+    import ctypes
+    ctx = mk(make_deck(40, 40, 8, 8, 4, seed=0))
+    ctx.rand_stream(0, 1)                                   # device tables built before libc's stream is read (HIP start-up may draw from it)
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1)
+    want = np.array([libc.rand() for _ in range(70000)], np.int32)
+    for off, n in ((0, 1), (0, 31), (0, 1000), (5, 62), (30, 33), (12345, 4097), (65536 - 7, 3000), (0, 70000)):
+        got = ctx.rand_stream(off, n)
+        assert np.array_equal(got, want[off:off + n]), (off, n, int(np.argmax(got != want[off:off + n])))
+
+
+BORDER_GEOMS = [(24, 20, 6, 5), (315, 195, 50, 50), (415, 295, 40, 40), (30, 40, 4, 9), (40, 30, 9, 4), (17, 23, 0, 6), (17, 23, 6, 0),
+                (12, 15, 2, 2), (9, 300, 3, 8), (300, 9, 20, 3)]
+
+
+@pytest.mark.parametrize("geom", BORDER_GEOMS, ids=lambda g: "x".join(map(str, g)))
+def test_device_border_model_equals_extendvel_linear(geom):
+    """fdw_dev_extendvel_linear for three consecutive shots against the oracle's extendvel_linear called three times on one rand() stream
+    (that oracle is pinned to the reference's functions.c by tests/test_oracle_golden.py): borders deeper than wide (the corner triangles then
+    overwrite border draws of interior columns), wider than deep (cells nothing writes), no border on one axis, several 256-column strips."""
+    nx, nz, nxb, nzb = geom
+    nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+    rng = np.random.default_rng(nx * 7 + nz)
+    vp = (1500 + 2500 * rng.random((nx, nz))).astype(np.float32)
+    ctx = F.FDWave(8, nxe, nze, nxb, nzb, 4, 0.75, 10.0, 10.0, 0.001, compat=True)
+    ctx.model_resident(vp)
+    T = ctx.border_draws()
+    assert T == nx * nzb + 2 * nz * nxb + 2 * nzb * (nzb + 1)
+    got = [ctx.dev_extendvel_linear(s * T, want_vel=True) for s in range(3)]
+    vpe = np.zeros((nxe, nze), np.float32)
+    vpe[nxb:nxb + nx, nzb:nzb + nz] = vp
+    for s in range(3):                                       # no HIP call between these: libc's stream is the oracle's alone
+        want = O.extendvel_linear(vpe, nx, nz, nxb, nzb, seed=1 if s == 0 else None).copy()
+        assert_bit_equal(got[s], want, f"extended model of shot {s}")
+    if nxb and nzb:
+        assert not np.array_equal(got[0], got[1])
+
+
+def test_shot_on_the_resident_model_equals_shot_on_the_uploaded_one():
+    nx, nz, nxb, nzb, nt = 70, 90, 12, 10, 30
+    nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+    rng = np.random.default_rng(5)
+    vp = (1500 + 2500 * rng.random((nx, nz))).astype(np.float32)
+    srce = F.ricker_wavelet(nt, 0.001, 30.0)
+    d_obs = rng.standard_normal((nx, nt)).astype(np.float32)
+    ctx = F.FDWave(8, nxe, nze, nxb, nzb, nt, 0.75, 10.0, 10.0, 0.001, compat=True)
+    with pytest.raises(F.FdwError):
+        ctx.dev_extendvel_linear(0)                          # no model yet
+    ctx.model_resident(vp)
+    with pytest.raises(F.FdwError):
+        ctx.shot_resident(nxb + 5, nzb + 2, nzb + 1, srce, d_obs)   # model uploaded, border not drawn yet
+    T = ctx.border_draws()
+    other = F.FDWave(8, nxe, nze, nxb, nzb, nt, 0.75, 10.0, 10.0, 0.001, compat=True)
+    orc = O.Oracle(8, nxe, nze, nxb, nzb, nt, 0.75, 10.0, 10.0, 0.001, compat=True)
+    for s in (0, 1, 4):
+        vel = ctx.dev_extendvel_linear(s * T, want_vel=True)
+        img, P, PP = ctx.shot_resident(nxb + 5 + s, nzb + 2, nzb + 1, srce, d_obs, want_fields=True)
+        v2 = vel * vel
+        img2, P2, PP2 = other.shot(v2, nxb + 5 + s, nzb + 2, nzb + 1, srce, d_obs, want_fields=True)
+        assert np.abs(img).max() > 0
+        assert_bit_equal(P, P2, "P"), assert_bit_equal(PP, PP2, "PP"), assert_bit_equal(img, img2, "image")
+        oP, oPP = orc.forward(v2, nxb + 5 + s, nzb + 2, srce)
+        assert_bit_equal(img, orc.back(v2, oP, oPP, d_obs, nzb + 1), "image vs oracle")
+    ctx.shot(v2, nxb + 5, nzb + 2, nzb + 1, srce, d_obs)     # a host model replaces the resident square ...
+    with pytest.raises(F.FdwError):
+        ctx.shot_resident(nxb + 5, nzb + 2, nzb + 1, srce, d_obs)   # ... so the resident shot refuses until the border is drawn again
+    with pytest.raises(F.FdwError):
+        F.FDWave(8, 40, 40, 1, 4, 4, 0.75, 10.0, 10.0, 0.001).model_resident(np.ones((38, 32), np.float32))   # nb - 1 = 0 in the ramp
