@@ -46,6 +46,9 @@ typedef struct {
     int ns, nworkers, is0, nb, nx, nt, sz, gz;
     const int *sx;
     const float *srce, *d_obs, *vel2_all;
+    const float *vp;      /* dev_border: the interior model every worker keeps resident in HBM */
+    long long draws;      /* rand() calls one extendvel_linear consumes */
+    int dev_border;
     float *imloc_all;
     size_t ne, ni;
     volatile int failed;
@@ -65,10 +68,23 @@ static void *shot_worker(void *p)
         j->failed = 1;
         return NULL;
     }
+    if (j->dev_border && fdw_model_resident(ctx, j->vp) != FDW_OK) {
+        fprintf(stderr, "fdw_model_resident: %s\n", fdw_last_error());
+        j->failed = 1;
+    }
     for (int b = a->w; b < j->nb && !j->failed; b += a->nw) {
         const int is = j->is0 + b;
-        if (fdw_shot(ctx, j->vel2_all + (size_t)b * j->ne, j->sx[is], j->sz, j->gz, j->srce, j->d_obs + (size_t)is * j->nx * j->nt,
-                     j->imloc_all + (size_t)b * j->ni, NULL, NULL) != FDW_OK) {
+        const float *d_obs = j->d_obs + (size_t)is * j->nx * j->nt;
+        float *imloc = j->imloc_all + (size_t)b * j->ni;
+        int rc;
+        if (j->dev_border) {
+            /* R:486-494 in HBM: shot `is` of the serial program consumes draws [is T, (is + 1) T) of the unseeded rand() stream */
+            rc = fdw_dev_extendvel_linear(ctx, (unsigned long long)is * (unsigned long long)j->draws, NULL);
+            if (rc == FDW_OK) rc = fdw_shot_resident(ctx, j->sx[is], j->sz, j->gz, j->srce, d_obs, imloc, NULL, NULL);
+        } else {
+            rc = fdw_shot(ctx, j->vel2_all + (size_t)b * j->ne, j->sx[is], j->sz, j->gz, j->srce, d_obs, imloc, NULL, NULL);
+        }
+        if (rc != FDW_OK) {
             fprintf(stderr, "fdw_shot: %s\n", fdw_last_error());
             j->failed = 1;
         }
@@ -158,6 +174,10 @@ int main(int argc, char **argv)
      * few percent of an MI355X: up to FDW_SHOT_WORKERS (default 4) host threads, each with its own context and stream, propagate
      * shots side by side.  What must stay serial does: the border model draws from ONE rand() stream in shot order (R:486), so all
      * squared-velocity models are built first, and the images are stacked (and image.num written) in shot order afterwards. */
+    /* The border model itself is generated on the device from the resident interior model (fdw_dev_extendvel_linear: the rand() stream is
+     * addressed by position, so no worker waits for another's draws); FDW_HOST_BORDER=1 or a geometry the device path refuses (a one-cell
+     * border) keeps the host loop below. */
+    const int dev_border = !vel_ext_flag && !getenv("FDW_HOST_BORDER") && nxb != 1 && nzb != 1 && nzb <= nxe;
     int nworkers = 4;
     if (getenv("FDW_SHOT_WORKERS")) nworkers = atoi(getenv("FDW_SHOT_WORKERS"));
     if (nworkers < 1) nworkers = 1;
@@ -172,10 +192,11 @@ int main(int argc, char **argv)
     shot_job job;
     job.prm = &prm; job.ns = ns; job.nworkers = nworkers; job.sx = sx; job.sz = sz; job.gz = gz; job.srce = srce; job.d_obs = d_obs;
     job.nx = nx; job.nt = nt; job.ne = ne; job.ni = ni; job.vel2_all = vel2_all; job.imloc_all = imloc_all; job.failed = 0;
+    job.vp = vp; job.draws = fdw_border_draws(nx, nz, nxb, nzb); job.dev_border = dev_border;
 
     for (int is0 = 0; is0 < ns; is0 += batch) {
         const int nb = is0 + batch <= ns ? batch : ns - is0;
-        for (int b = 0; b < nb; b++) {               /* models in shot order: the rand() stream is sequential */
+        for (int b = 0; b < nb && !dev_border; b++) { /* models in shot order: the rand() stream is sequential */
             const int is = is0 + b;
             const float *v = vpe;
             if (vel_ext_flag)

@@ -7,8 +7,10 @@ with the shots dealt round-robin to the GPUs of a node, one process per GPU.
 Shots are independent (the reference has no multi-GPU path; this is the embarrassingly parallel axis of
 SURVEY.md section 8e).  Every rank reads the deck and the inputs, runs `fdw_shot` for its shots, and rank 0
 stacks the per-shot images IN SHOT ORDER, so `dir.image` is bit-identical to the single-GPU program whatever
-N is (an all-reduce would change the fp32 summation order).  The unseeded-rand() border model is replayed
-on every rank for all shots so that shot s sees exactly the stream state the serial program would give it.
+N is (an all-reduce would change the fp32 summation order).  The unseeded-rand() border model is generated on
+the device from the resident interior model (`fdw_dev_extendvel_linear`): the stream is addressed by position, so
+shot s draws exactly what the serial program would give it without any rank replaying the shots before it
+(FDW_HOST_BORDER=1 or a one-cell border: the host loop, replayed on every rank).
 Outputs are the reference's: <tmpdir>/dir.image, dir.image_lap (zeros), empty dir.snaps*, ./image.num.
 """
 import ctypes as C
@@ -94,23 +96,31 @@ def run(deck_path, out=sys.stdout):
     nworkers = max(1, int(os.environ.get("FDW_SHOT_WORKERS", "2")))
     local_ctx = threading.local()
 
+    dev_border = vel_ext is None and "FDW_HOST_BORDER" not in os.environ and nxb != 1 and nzb != 1 and nzb <= nxe
+
     def one_shot(s, v2):
         if not hasattr(local_ctx, "ctx"):
             local_ctx.ctx = api.FDWave(d["order"], nxe, nze, nxb, nzb, nt, d["fac"], d["dx"], d["dz"], d["dt"], compat=True, device=local)
-        return s, local_ctx.ctx.shot(v2, sx[s], sz, gz, srce, np.ascontiguousarray(d_obs[s]))
+            if dev_border:
+                local_ctx.ctx.model_resident(vp)
+        ctx = local_ctx.ctx
+        if dev_border:          # fd-code.cu:486-494 in HBM; shot s of the serial program consumes draws [s T, (s + 1) T)
+            ctx.dev_extendvel_linear(s * ctx.border_draws())
+            return s, ctx.shot_resident(sx[s], sz, gz, srce, np.ascontiguousarray(d_obs[s]))
+        return s, ctx.shot(v2, sx[s], sz, gz, srce, np.ascontiguousarray(d_obs[s]))
 
     mine, pending = {}, []
     with concurrent.futures.ThreadPoolExecutor(max_workers=nworkers) as pool:
         for s in range(ns):
             if vel_ext is not None:
                 v = np.asarray(vel_ext[s])
-            else:
+            elif not dev_border:
                 api.extendvel_linear(vpe, nx, nz, nxb, nzb)        # every rank replays the whole rand() stream (fd-code.cu:486)
                 v = vpe
             if s % world != rank:
                 continue
             print(f"** source {s + 1}, at ({sx[s] - nxb},{sz - nzb}) " + (f" [rank {rank}]" if world > 1 else ""), file=out, flush=True)
-            pending.append(pool.submit(one_shot, s, (v * v).astype(np.float32)))
+            pending.append(pool.submit(one_shot, s, None if dev_border else (v * v).astype(np.float32)))
         for f in pending:
             s, im = f.result()
             mine[s] = im
