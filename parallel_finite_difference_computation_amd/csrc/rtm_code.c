@@ -93,10 +93,20 @@ static void *shot_worker(void *p)
     return NULL;
 }
 
+static double now_s(void)
+{
+    struct timeval t;
+    gettimeofday(&t, NULL);
+    return t.tv_sec + t.tv_usec * 1e-6;
+}
+
 int main(int argc, char **argv)
 {
     struct timeval start, end;
     gettimeofday(&start, NULL);
+    const int timing = getenv("FDW_TIMING") != NULL;   /* phase times on stderr */
+    double t_shots = 0.0, t_stack = 0.0;
+    const double t_begin = now_s();
     if (argc < 2) {
         fprintf(stderr, "usage: %s <input.dat>\n", argv[0]);
         return EXIT_FAILURE;
@@ -206,6 +216,7 @@ int main(int argc, char **argv)
             float *v2 = vel2_all + (size_t)b * ne;
             for (size_t k = 0; k < ne; k++) v2[k] = v[k] * v[k]; /* R:490-494 */
         }
+        const double t0 = now_s();
         job.is0 = is0; job.nb = nb;
         memset(imloc_all, 0, (size_t)nb * ni * sizeof(float));                                 /* R:515 */
         const int nw = nb < nworkers ? nb : nworkers;
@@ -221,6 +232,8 @@ int main(int argc, char **argv)
         shot_worker(&wa[0]);
         for (int w = 1; w < nw; w++) pthread_join(th[w], NULL);
         if (job.failed) return EXIT_FAILURE;
+        const double t1 = now_s();
+        t_shots += t1 - t0;
         for (int b = 0; b < nb; b++) {               /* R:480-529 in shot order */
             const int is = is0 + b;
             const float *imloc = imloc_all + (size_t)b * ni;
@@ -235,7 +248,11 @@ int main(int argc, char **argv)
                     fprintf(fnum, " %f \n", img[(size_t)ix * nz + iz]);
                 }
         }
+        t_stack += now_s() - t1;
     }
+    if (timing)
+        fprintf(stderr, "[timing] total %.3f s: shots (contexts, border models, propagation) %.3f s, stacking + image.num %.3f s, rest (deck, inputs) %.3f s\n",
+                now_s() - t_begin, t_shots, t_stack, now_s() - t_begin - t_shots - t_stack);
     /* opt-in extension (deck key image_lap=1): fill dir.image_lap with the reference's own offline filter (models/3lay_mod/laplace.f90)
      * of the stacked image instead of the zeros the reference writes (R:477, R:542) */
     if (fdw_deck_int(deck, "image_lap") == 1 && fdw_image_laplacian(0, img, nx, nz, dx, dz, img_lap) != FDW_OK) {
