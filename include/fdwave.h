@@ -210,8 +210,18 @@ int fdw_download_field(fdw_ctx *ctx, float *h_dst, const float *d_src);
  *                           draws [draw_offset, draw_offset + T) of the seed-1 stream
  * fdw_shot_resident         fdw_shot (R:496-520) on the resident vel2; FDW_ESTATE if a host model was uploaded since
  * fdw_rand_stream           out[i] = draw number draw_offset + i of that stream, produced by the device generator (tests)
+ * fdw_shot_batch            `nshots` consecutive shots of the reference's loop (R:480-520) through ONE launch per time step: shot b has
+ *                           source row sx0 + b dsx (R:405-407), gather d_obs + b nx nt, image imloc + b nx nz (accumulated into, as
+ *                           fdw_shot does), model v2_all + b nxe nze or, v2_all == NULL, the border model of draws
+ *                           [draw_offset + b T, ...) drawn on the device.  Results are those of the shots run one by one, bit for bit;
+ *                           contexts whose regime the batched launches do not cover (large grids, orders above 8, receiver rows
+ *                           outside the truncated extents) run them one by one.
+ * fdw_shot_batch_max        batch size that fills the chip for this geometry (1: batching gains nothing)
  */
 long long fdw_border_draws(int nx, int nz, int nxb, int nzb);
+int fdw_shot_batch(fdw_ctx *ctx, int nshots, const float *v2_all, unsigned long long draw_offset, int sx0, int dsx, int sz, int gz,
+                   const float *srce, const float *d_obs, float *imloc);
+int fdw_shot_batch_max(const fdw_ctx *ctx);
 int fdw_model_resident(fdw_ctx *ctx, const float *vp);
 int fdw_dev_extendvel_linear(fdw_ctx *ctx, unsigned long long draw_offset, float *vel_out);
 int fdw_shot_resident(fdw_ctx *ctx, int sx, int sz, int gz, const float *srce, const float *d_obs, float *imloc, float *P, float *PP);

@@ -209,6 +209,19 @@ class FDWave:
                                       P.ctypes.data if want_fields else None, PP.ctypes.data if want_fields else None))
         return (imloc, P, PP) if want_fields else imloc
 
+    def shot_batch(self, nshots, sx0, dsx, sz, gz, srce, d_obs, v2_all=None, draw_offset=0, imloc=None):
+        """`nshots` consecutive shots of rtm_code's loop (fd-code.cu:480-520) through one launch per time step.  d_obs[nshots][nx][nt];
+        v2_all[nshots][nxe][nze], or None = border models drawn on the device from the resident interior model at draws
+        draw_offset + b * border_draws().  Returns imloc[nshots][nx][nz]."""
+        imloc = np.zeros((nshots, self.nx, self.nz), np.float32) if imloc is None else np.array(imloc, np.float32, order="C")
+        v2p = None if v2_all is None else _f32(v2_all, (nshots, self.nxe, self.nze)).ctypes.data
+        check(lib().fdw_shot_batch(self._h, nshots, v2p, int(draw_offset), sx0, dsx, sz, gz, _f32(srce, (self.nt,)),
+                                   _f32(d_obs, (nshots, self.nx, self.nt)), imloc))
+        return imloc
+
+    def shot_batch_max(self):
+        return int(lib().fdw_shot_batch_max(self._h))
+
     def rand_stream(self, draw_offset, n):
         """Draws [draw_offset, draw_offset + n) of the unseeded glibc rand() stream as the device generator produces them."""
         out = np.zeros(n, np.int32)

@@ -80,6 +80,10 @@ struct fdw_ctx {
     unsigned* d_jump = nullptr;
     int njump = 0;
     bool model_resident = false, v2_resident = false;
+    // a batch of shots through one launch per time step (fdw_shot_batch): per-shot copies of the eight fields, v2, image, gather
+    int nbatch = 1, batch_dsx = 0, batch_cap = 0;
+    float* bfld[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float *b_v2 = nullptr, *b_img = nullptr, *b_dobs = nullptr;
     int no_fused_back = 0;   // experiments / tests: backward iterations as two launches (source step, receiver step) -- FDW_NO_FUSED_BACK=1
 };
 
@@ -300,7 +304,8 @@ extern "C" void fdw_destroy(fdw_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     float* bufs[] = {c->d_taperz, c->d_txfac, c->d_gcx, c->d_gcz, c->fld[0], c->fld[1], c->fld[2], c->fld[3],
                      c->fld[4], c->fld[5], c->fld[6], c->fld[7], c->d_v2, c->d_img, c->d_srce, c->d_dobs, c->d_rec,
-                     c->d_vp, c->d_vpe, (float*)c->d_draws, (float*)c->d_jump};
+                     c->d_vp, c->d_vpe, (float*)c->d_draws, (float*)c->d_jump, c->bfld[0], c->bfld[1], c->bfld[2], c->bfld[3],
+                     c->bfld[4], c->bfld[5], c->bfld[6], c->bfld[7], c->b_v2, c->b_img, c->b_dobs};
     for (float* b : bufs)
         if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -314,7 +319,7 @@ extern "C" void fdw_destroy(fdw_ctx* c)
 static int ring_rows(int h, int pf) { return ((2 * h + pf + pf - 1) / pf) * pf; }
 static int effective_prefetch(const fdw_ctx* c) { return (c->h == 4 && c->prefetch >= 1 && c->prefetch <= 3) ? c->prefetch : 2; }
 
-static void fill_geometry(const fdw_ctx* c, StepArgs& a, int rows)
+static void fill_geometry(const fdw_ctx* c, StepArgs& a, int rows, int batch = 1)
 {
     const int nstrips = (c->pitch + 255) / 256;
     int wz = c->wz;
@@ -329,7 +334,7 @@ static void fill_geometry(const fdw_ctx* c, StepArgs& a, int rows)
         //   Infinity-Cache-resident grids (4096^2): 24 rows
         //   small decks (new_mod 415x295 ... 2048^2): as many waves as the grid gives, down to ONE row per
         //   wave -- a launch is a latency chain (prologue + rows), 5.1 us/step at 1 row vs 12.7 at 8 on new_mod
-        const long strip_rows = (long)rows * nstrips;
+        const long strip_rows = (long)rows * nstrips * batch;   // a batch of shots counts as one grid of that many rows
         if (strip_rows >= 200000) xchunk = ring_rows(c->h, effective_prefetch(c));
         else if (strip_rows >= 60000) xchunk = 24;   // 4096^2 class (Infinity-Cache resident)
         else xchunk = (int)std::min<long>(std::max<long>((strip_rows + 4095) / 4096, 1), 10);   // >= ~4096 waves, down to 1 row each;
@@ -413,9 +418,15 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
         a.cz[io] = io <= c->prm.order ? c->cz[io] : 0.0f;
     }
     if (a.r1 <= a.r0) return FDW_OK;
+    if (c->nbatch > 1) {      // fdw_shot_batch: shot b = these pointers + b fields, its own gather, its own source row
+        a.nbatch = c->nbatch;
+        a.bstride = (long long)field_elems(c);
+        a.inj_bstride = mode == FDW_MODE_FWD ? 0 : (long long)c->nx * c->prm.nt;
+        a.inj_dx = mode == FDW_MODE_FWD ? c->batch_dsx : 0;
+    }
     hipError_t e;
     if (c->h <= kMaxFastHalfOrder && !c->use_generic) {
-        fill_geometry(c, a, a.r1 - a.r0);
+        fill_geometry(c, a, a.r1 - a.r0, std::max(c->nbatch, 1));
         e = launch_step_fast(a, c->h, mode, effective_prefetch(c), s);
     } else {
         if (mode >= FDW_MODE_MOD) return fail(FDW_EINVAL, "step: mode %d has no generic-order kernel", mode);
@@ -1408,4 +1419,134 @@ extern "C" int fdw_shot_resident(fdw_ctx* c, int sx, int sz, int gz, const float
     if (!c) return fail(FDW_EINVAL, "ctx is NULL");
     if (!c->v2_resident) return fail(FDW_ESTATE, "no resident squared model: call fdw_dev_extendvel_linear first");
     return shot_impl(c, nullptr, sx, sz, gz, srce, d_obs, imloc, P, PP);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a batch of shots through ONE launch per time step
+// ------------------------------------------------------------------------------------------------
+// A shot of a deck of the reference's size (new_mod: 495 x 375 extended) is 3400 dependent launches of kernels that fill a few percent
+// of the chip and last 3.5-7 us each: latency, not bandwidth.  Shots are independent (R:480-529 couples them only through the image sum),
+// so `nshots` of them on one geometry go through the same launches side by side: gridDim.y = shot, every field pointer offset by
+// shot * field, the gather by shot * nx * nt, the source row by shot * dsx (the reference's sx = fsx + is * ds, R:405-407).
+static bool batch_ok(const fdw_ctx* c)
+{
+    return c->prm.dialect == FDW_DIALECT_RTM && c->h <= kMaxFastHalfOrder && !c->use_generic && !c->no_fused_back && !two_step_pays(c) &&
+           !pipe_pays(c) && c->prm.nxb + c->nx <= c->upd_x1 /* no receiver rows outside the time-stepped extent */;
+}
+
+extern "C" int fdw_shot_batch_max(const fdw_ctx* c)
+{
+    if (!c || !is_full_grid(c) || !batch_ok(c)) return 1;
+    const long waves = (long)c->nxl * ((c->pitch + 255) / 256);        // one-row-per-wave regime: waves one shot launches
+    const long by_fill = 16384 / std::max<long>(waves, 1);            // ~16 waves per SIMD in flight across the chip
+    const long by_mem = (long)(((size_t)6 << 30) / (11 * field_elems(c) * sizeof(float)));
+    return (int)std::max<long>(1, std::min<long>({by_fill, by_mem, 64}));
+}
+
+static int ensure_batch_buffers(fdw_ctx* c, int n)
+{
+    const size_t nx = c->nx, nt = std::max(c->prm.nt, 1);
+    if (c->batch_cap >= n) return FDW_OK;
+    float** all[] = {&c->bfld[0], &c->bfld[1], &c->bfld[2], &c->bfld[3], &c->bfld[4], &c->bfld[5], &c->bfld[6], &c->bfld[7], &c->b_v2, &c->b_img, &c->b_dobs};
+    for (float** q : all) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    c->batch_cap = 0;
+    for (float** q : all) {
+        const size_t elems = (q == &c->b_dobs ? nx * nt : field_elems(c)) * (size_t)n;
+        hipError_t e = hipMalloc((void**)q, elems * sizeof(float));
+        if (e != hipSuccess) return fail(FDW_ENOMEM, "hipMalloc(%zu bytes) failed: %s", elems * sizeof(float), hipGetErrorString(e));
+        HIP_TRY(hipMemset(*q, 0, elems * sizeof(float)));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    c->batch_cap = n;
+    return FDW_OK;
+}
+
+namespace {
+struct BatchScope {      // the context's single-shot buffers step aside for the batch ones while a batch runs
+    fdw_ctx* c;
+    explicit BatchScope(fdw_ctx* ctx, int n, int dsx) : c(ctx) { swap(); c->nbatch = n; c->batch_dsx = dsx; }
+    ~BatchScope() { swap(); c->nbatch = 1; c->batch_dsx = 0; }
+    void swap()
+    {
+        for (int i = 0; i < 8; i++) std::swap(c->fld[i], c->bfld[i]);
+        std::swap(c->d_v2, c->b_v2);
+        std::swap(c->d_img, c->b_img);
+        std::swap(c->d_dobs, c->b_dobs);
+    }
+};
+}  // namespace
+
+extern "C" int fdw_shot_batch(fdw_ctx* c, int nshots, const float* v2_all, unsigned long long draw_offset, int sx0, int dsx, int sz, int gz,
+                              const float* srce, const float* d_obs, float* imloc)
+{
+    if (!c || !srce || !d_obs || !imloc) return fail(FDW_EINVAL, "NULL argument");
+    if (nshots < 1) return fail(FDW_EINVAL, "nshots=%d", nshots);
+    if (!is_full_grid(c)) return fail(FDW_EINVAL, "fdw_shot_batch needs a full-grid context");
+    if (c->nx <= 0 || c->nz <= 0) return fail(FDW_EINVAL, "no interior to image");
+    if (!v2_all && !c->model_resident) return fail(FDW_ESTATE, "no model: pass v2_all or call fdw_model_resident first");
+    const int nt = c->prm.nt;
+    const size_t ni = (size_t)c->nx * c->nz, ne = (size_t)c->prm.nxe * c->prm.nze, ng = (size_t)c->nx * nt, fe = field_elems(c);
+    const int sx_last = sx0 + (nshots - 1) * dsx;
+    if (std::min(sx0, sx_last) < 0 || std::max(sx0, sx_last) >= c->prm.nxe || std::max(sx0, sx_last) >= c->upd_x1)
+        return fail(FDW_EINVAL, "source rows %d..%d leave the rows the reference time-steps (< %d)", sx0, sx_last, c->upd_x1);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if (nshots == 1 || !batch_ok(c)) {      // nothing to gain or a regime the batched launches do not cover: the shots one after the other
+        for (int b = 0; b < nshots; b++) {
+            if (!v2_all && (rc = fdw_dev_extendvel_linear(c, draw_offset + (unsigned long long)b * fdw_border_draws(c->nx, c->nz, c->prm.nxb, c->prm.nzb), nullptr)))
+                return rc;
+            if ((rc = shot_impl(c, v2_all ? v2_all + b * ne : nullptr, sx0 + b * dsx, sz, gz, srce, d_obs + b * ng, imloc + b * ni, nullptr, nullptr))) return rc;
+        }
+        return FDW_OK;
+    }
+    if ((rc = ensure_work_buffers(c, 8, true)) || (rc = ensure_batch_buffers(c, nshots)) || (rc = upload_source(c, srce, nt))) return rc;
+    hipStream_t s = c->stream;
+    // gathers [shot][nx][nt] -> [shot][nt][nx]
+    {
+        std::vector<float> t(ng * nshots);
+        for (int b = 0; b < nshots; b++)
+            for (size_t i = 0; i < (size_t)c->nx; i++)
+                for (size_t k = 0; k < (size_t)nt; k++) t[b * ng + k * c->nx + i] = d_obs[b * ng + i * nt + k];
+        HIP_TRY(hipMemcpy(c->b_dobs, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    const long long draws = fdw_border_draws(c->nx, c->nz, c->prm.nxb, c->prm.nzb);
+    for (int b = 0; b < nshots; b++) {
+        if (v2_all) {
+            HIP_TRY(hipMemcpy2DAsync(c->b_v2 + b * fe, (size_t)c->pitch * sizeof(float), v2_all + b * ne, (size_t)c->prm.nze * sizeof(float),
+                                     (size_t)c->prm.nze * sizeof(float), c->nxl, hipMemcpyHostToDevice, s));
+        } else {
+            hipError_t e = launch_rand_stream(window_at(kGlibcDiscard + draw_offset + (unsigned long long)b * draws), c->d_jump, c->njump, draws, c->d_draws, s);
+            if (e == hipSuccess) {
+                BorderArgs ba{c->d_vp, c->d_draws, nullptr, c->b_v2 + b * fe, c->nx, c->nz, c->prm.nxb, c->prm.nzb, c->pitch};
+                e = launch_extendvel(ba, s);
+            }
+            if (e != hipSuccess) return fail(FDW_EHIP, "border model launch failed: %s", hipGetErrorString(e));
+        }
+    }
+    for (int i = 0; i < 8; i++) HIP_TRY(hipMemsetAsync(c->bfld[i], 0, fe * nshots * sizeof(float), s));    // R:496-497, R:511-514
+    HIP_TRY(hipMemsetAsync(c->b_img, 0, fe * nshots * sizeof(float), s));
+    for (int b = 0; b < nshots; b++)
+        HIP_TRY(hipMemcpy2DAsync(c->b_img + b * fe + (size_t)c->prm.nxb * c->pitch + c->prm.nzb, (size_t)c->pitch * sizeof(float), imloc + b * ni,
+                                 (size_t)c->nz * sizeof(float), (size_t)c->nz * sizeof(float), c->nx, hipMemcpyHostToDevice, s));
+    {
+        BatchScope scope(c, nshots, dsx);
+        int ip = 0, ipp = 1;
+        if ((rc = fdw_dev_steps2(c, c->fld, c->d_v2, c->d_srce, sx0, sz, 0, nt, 0, &ip, &ipp, s))) return rc;
+        for (int b = 0; b < nshots && nt > 0; b++)
+            if ((rc = fdw_dev_taper_finalize(c, c->fld[ip] + b * fe, s))) return rc;
+        float *d_p = c->fld[ip], *d_pp = c->fld[ipp];
+        float* src[4] = {d_p, d_pp, nullptr, nullptr};
+        for (int i = 0, n = 2; i < 4; i++)
+            if (c->fld[i] != d_p && c->fld[i] != d_pp) src[n++] = c->fld[i];
+        float* const rcv[4] = {c->fld[4], c->fld[5], c->fld[6], c->fld[7]};
+        if ((rc = back_loop(c, src, rcv, gz, nt))) return rc;
+    }
+    for (int b = 0; b < nshots; b++)
+        HIP_TRY(hipMemcpy2DAsync(imloc + b * ni, (size_t)c->nz * sizeof(float), c->b_img + b * fe + (size_t)c->prm.nxb * c->pitch + c->prm.nzb,
+                                 (size_t)c->pitch * sizeof(float), (size_t)c->nz * sizeof(float), c->nx, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return FDW_OK;
 }

@@ -49,6 +49,10 @@ struct StepArgs {
     float gw[4][4];        // expf(-(i*i + j*j)): the 7x7 Gaussian point source of ptsrc.c:49-55
     float* rec;            // this step's trace samples [rec_n]: rec[r - rec_x0] = p(r, rec_z)   (mod_main.cpp:155-157)
     int rec_z, rec_x0, rec_n;
+    // batch of independent shots on one geometry (gridDim.y = shots; 0 / 1 = a single shot): shot b works on field pointers + b * bstride,
+    // samples inj + b * inj_bstride, source row inj_x + b * inj_dx
+    long long bstride, inj_bstride;
+    int inj_dx, nbatch;
 };
 
 // Two-steps-per-pass kernel (temporal blocking, order 8, forward mode): see fdw_step2_kernel.

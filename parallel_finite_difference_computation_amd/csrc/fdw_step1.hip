@@ -25,11 +25,23 @@ namespace fdw {
 // >= nze-H.  Edge handling (masks, damping, injection) is wave-uniform branches around VALU / scalar
 // loads only.
 // ------------------------------------------------------------------------------------------------
+// the field pointers, sample pointer and source row of the shot a block works on (shot 0: the launch arguments themselves)
+struct ShotView {
+    const float* p;
+    float* pp;
+    const float* v2;
+    const float* psrc;
+    float* fpp;
+    float* img;
+    const float* inj;
+    int inj_x;
+};
+
 template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false, bool BACK = false>
-__device__ __forceinline__ void march(const StepArgs& a, const int lane, const int zs, const int xa, const int xe)
+__device__ __forceinline__ void march(const StepArgs& a, const ShotView& sv, const int lane, const int zs, const int xa, const int xe)
 {
     // BACK: one whole backward iteration of fd_back (R:317-329) in a single pass: the source field is reconstructed in a second
-    // register ring (a.psrc = F_{k-1} read only, a.fpp = F_{k-2} overwritten with F_k: kernel_lap + kernel_time without damping,
+    // register ring (sv.psrc = F_{k-1} read only, sv.fpp = F_{k-2} overwritten with F_k: kernel_lap + kernel_time without damping,
     // R:317-318) next to the receiver step, v2 is read once for both and F_k meets the new receiver row in registers for the imaging
     // condition instead of travelling through memory.
     using G = RingGeom<H, PF>;
@@ -55,10 +67,10 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
     const bool wave_tap = TAPER && (zs - 4 < a.ztap);
     const bool xtap = wave_tap && ((xa - H < a.xt_lo) || (xe + H > a.xt_hi));   // rows with an x factor / no z factor
     bool inj_here = false;
-    if (INJ == 1) inj_here = (a.inj_x >= xa) && (a.inj_x < xe) && (a.inj_z >= zs) && (a.inj_z < zs + 256);
-    if (INJ == 2) inj_here = (a.inj_z >= zs) && (a.inj_z < zs + 256) && (a.inj_x < xe) && (a.inj_x + a.inj_n > xa);
-    if (INJ == 3) inj_here = (a.inj_z + 3 >= zs) && (a.inj_z - 3 < zs + 256) && (a.inj_x + 3 >= xa) && (a.inj_x - 3 < xe);   // 7x7 blob
-    const float inj_src = ((INJ == 1 || INJ == 3) && inj_here) ? sload(a.inj, 0) : 0.0f;
+    if (INJ == 1) inj_here = (sv.inj_x >= xa) && (sv.inj_x < xe) && (a.inj_z >= zs) && (a.inj_z < zs + 256);
+    if (INJ == 2) inj_here = (a.inj_z >= zs) && (a.inj_z < zs + 256) && (sv.inj_x < xe) && (sv.inj_x + a.inj_n > xa);
+    if (INJ == 3) inj_here = (a.inj_z + 3 >= zs) && (a.inj_z - 3 < zs + 256) && (sv.inj_x + 3 >= xa) && (sv.inj_x - 3 < xe);   // 7x7 blob
+    const float inj_src = ((INJ == 1 || INJ == 3) && inj_here) ? sload(sv.inj, 0) : 0.0f;
     const bool rec_here = DD && (a.rec != nullptr) && (a.rec_z >= zs) && (a.rec_z < zs + 256);
     const CoefPairs<H> cpk = coef_pairs<H>(a.cx, a.cz);
 
@@ -100,16 +112,16 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
     };
 
     // ---- loaders: unconditional, clamped --------------------------------------------------------
-    auto load_p = [&](int row) -> f4 { return f4_load(a.p + (size_t)min(max(row, 0), rowmax) * pitch, voff); };
+    auto load_p = [&](int row) -> f4 { return f4_load(sv.p + (size_t)min(max(row, 0), rowmax) * pitch, voff); };
     auto load_halo = [&](int row) -> f4 {
 #if FDW_ABL_BITS & 2
         return f4_zero();
 #endif
-        return f4_load(a.p + (size_t)row * pitch, hoff);
+        return f4_load(sv.p + (size_t)row * pitch, hoff);
     };
     auto load_plain = [&](const float* base, int row) -> f4 { return f4_load_stream(base + (size_t)row * pitch, voff); };
-    auto load_f = [&](int row) -> f4 { return f4_load(a.psrc + (size_t)min(max(row, 0), rowmax) * pitch, voff); };
-    auto load_fhalo = [&](int row) -> f4 { return f4_load(a.psrc + (size_t)row * pitch, hoff); };
+    auto load_f = [&](int row) -> f4 { return f4_load(sv.psrc + (size_t)min(max(row, 0), rowmax) * pitch, voff); };
+    auto load_fhalo = [&](int row) -> f4 { return f4_load(sv.psrc + (size_t)row * pitch, hoff); };
 
     // ---- prologue: ring rows xa-H .. xa-H+R-1; pointwise rows xa .. xa+PF-1 --------------------
     // Issue order matters: the loop-header s_waitcnt is the stricter of (prologue state, end-of-turn
@@ -136,16 +148,16 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
             const int row = min(xa + m, xe - 1);
             qhal[m] = load_halo(row);
             if constexpr (!LAPONLY) {
-                qpp[m] = load_plain(a.pp, row);
-                qv2[m] = load_plain(a.v2, row);
+                qpp[m] = load_plain(sv.pp, row);
+                qv2[m] = load_plain(sv.v2, row);
             }
             if constexpr (IMG) {
-                if constexpr (!BACK) qps[m] = load_plain(a.psrc, row);
-                qim[m] = load_plain(a.img, row);
+                if constexpr (!BACK) qps[m] = load_plain(sv.psrc, row);
+                qim[m] = load_plain(sv.img, row);
             }
             if constexpr (BACK) {
                 fqhal[m] = load_fhalo(row);
-                fqpp[m] = load_plain(a.fpp, row);
+                fqpp[m] = load_plain(sv.fpp, row);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -233,17 +245,17 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
             }
             if constexpr (INJ != 0) {
                 if (inj_here) {   // wave-uniform, rare
-                    const bool injrow = (INJ == 1) ? (r == a.inj_x) : ((r >= a.inj_x) && (r < a.inj_x + a.inj_n));
+                    const bool injrow = (INJ == 1) ? (r == sv.inj_x) : ((r >= sv.inj_x) && (r < sv.inj_x + a.inj_n));
                     if (injrow) {
-                        const float injv = (INJ == 1) ? inj_src : sload(a.inj, r - a.inj_x);
+                        const float injv = (INJ == 1) ? inj_src : sload(sv.inj, r - sv.inj_x);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) res.v[e] = ihit[e] ? res.v[e] + injv : res.v[e];
                     }
                 }
             }
             if constexpr (INJ == 3) {
-                if (inj_here && r >= a.inj_x - 3 && r <= a.inj_x + 3) {   // ptsrc.c:49-55: s += ts * exp(-xn*xn - zn*zn), all float
-                    const int dxa = r > a.inj_x ? r - a.inj_x : a.inj_x - r;
+                if (inj_here && r >= sv.inj_x - 3 && r <= sv.inj_x + 3) {   // ptsrc.c:49-55: s += ts * exp(-xn*xn - zn*zn), all float
+                    const int dxa = r > sv.inj_x ? r - sv.inj_x : sv.inj_x - r;
                     const float g0 = a.gw[dxa][0], g1 = a.gw[dxa][1], g2 = a.gw[dxa][2], g3 = a.gw[dxa][3];   // wave-uniform kernarg reads
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -293,13 +305,13 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
             if (res.v[0] == 123.456f)
 #endif
             if (!partial) {
-                f4_store(a.pp + (size_t)r * pitch, voff, res);
-                if constexpr (IMG) f4_store(a.img + (size_t)r * pitch, voff, imr);
-                if constexpr (BACK) f4_store(a.fpp + (size_t)r * pitch, voff, fres);
+                f4_store(sv.pp + (size_t)r * pitch, voff, res);
+                if constexpr (IMG) f4_store(sv.img + (size_t)r * pitch, voff, imr);
+                if constexpr (BACK) f4_store(sv.fpp + (size_t)r * pitch, voff, fres);
             } else if (act) {
-                f4_store(a.pp + (size_t)r * pitch, voff, res);
-                if constexpr (IMG) f4_store(a.img + (size_t)r * pitch, voff, imr);
-                if constexpr (BACK) f4_store(a.fpp + (size_t)r * pitch, voff, fres);
+                f4_store(sv.pp + (size_t)r * pitch, voff, res);
+                if constexpr (IMG) f4_store(sv.img + (size_t)r * pitch, voff, imr);
+                if constexpr (BACK) f4_store(sv.fpp + (size_t)r * pitch, voff, fres);
             }
 
             // ---- refill the slots this row just freed (look-ahead loads) ----------------------
@@ -308,16 +320,16 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
                 const int nr = min(r + PF, xe - 1);
                 qhal[Q] = load_halo(nr);
                 if constexpr (!LAPONLY) {
-                    qpp[Q] = load_plain(a.pp, nr);
-                    qv2[Q] = load_plain(a.v2, nr);
+                    qpp[Q] = load_plain(sv.pp, nr);
+                    qv2[Q] = load_plain(sv.v2, nr);
                 }
                 if constexpr (IMG) {
-                    if constexpr (!BACK) qps[Q] = load_plain(a.psrc, nr);
-                    qim[Q] = load_plain(a.img, nr);
+                    if constexpr (!BACK) qps[Q] = load_plain(sv.psrc, nr);
+                    qim[Q] = load_plain(sv.img, nr);
                 }
                 if constexpr (BACK) {
                     fqhal[Q] = load_fhalo(nr);
-                    fqpp[Q] = load_plain(a.fpp, nr);
+                    fqpp[Q] = load_plain(sv.fpp, nr);
                 }
             }
             if constexpr (BACK) fring[U] = load_f(r - H + R);
@@ -340,6 +352,10 @@ __device__ __forceinline__ void march(const StepArgs& a, const int lane, const i
 template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false, bool BACK = false>
 __global__ __launch_bounds__(256) void fdw_step_kernel(const StepArgs a)
 {
+    // a batch of independent shots of one geometry fills the chip where one small grid cannot: blockIdx.y picks the shot
+    const int shot = blockIdx.y;
+    const long long o = shot * a.bstride;
+    const ShotView sv{a.p + o, a.pp + o, a.v2 + o, a.psrc + o, a.fpp + o, a.img + o, a.inj + shot * a.inj_bstride, a.inj_x + shot * a.inj_dx};
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(256) void fdw_step_kernel(const StepArgs a)
     const int xa = a.r0 + chunk * a.xchunk;
     const int xe = min(xa + a.xchunk, a.r1);
     if (xa >= xe) return;
-    march<H, TAPER, INJ, IMG, LAPONLY, PF, DD, BACK>(a, lane, zs, xa, xe);
+    march<H, TAPER, INJ, IMG, LAPONLY, PF, DD, BACK>(a, sv, lane, zs, xa, xe);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -484,7 +500,7 @@ __global__ void fdw_selftest_kernel(const float* src, float* out)
 template <int H, int PF>
 static hipError_t launch_fast_hp(const StepArgs& a, int mode, hipStream_t s)
 {
-    const dim3 grid(8 * a.nper), block(256);
+    const dim3 grid(8 * a.nper, a.nbatch > 1 ? a.nbatch : 1), block(256);
     switch (mode) {
     case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_step_kernel<H, true, 1, false, false, PF>), grid, block, 0, s, a); break;
     case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_step_kernel<H, false, 0, false, false, PF>), grid, block, 0, s, a); break;

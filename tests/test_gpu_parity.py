@@ -1031,3 +1031,41 @@ def test_shot_on_the_resident_model_equals_shot_on_the_uploaded_one():
         ctx.shot_resident(nxb + 5, nzb + 2, nzb + 1, srce, d_obs)   # ... so the resident shot refuses until the border is drawn again
     with pytest.raises(F.FdwError):
         F.FDWave(8, 40, 40, 1, 4, 4, 0.75, 10.0, 10.0, 0.001).model_resident(np.ones((38, 32), np.float32))   # nb - 1 = 0 in the ramp
+
+
+# ---- a batch of shots through one launch per time step ------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [(8, 70, 90, 12, 10, 30, True, 5, 3), (8, 61, 300, 17, 13, 21, True, 3, -7), (4, 50, 44, 9, 8, 16, False, 4, 2),
+                                  (8, 40, 36, 8, 8, 12, True, 7, 0), (10, 50, 44, 9, 8, 10, True, 2, 4), (8, 41, 37, 3, 0, 9, True, 3, 1)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_shot_batch_equals_the_shots_one_by_one(case):
+    """fdw_shot_batch (gridDim.y = shot: every launch of the forward and backward loops advances all shots of the batch) against the
+    same shots through fdw_shot_resident / fdw_shot one at a time, bit for bit: device-drawn and host-given models, source rows stepping
+    up, down and not at all, several strips, order 4, and two contexts the batched launches do not cover (order 10; receiver rows
+    outside the truncated extents), which must fall back to running the shots one by one."""
+    order, nx, nz, nxb, nzb, nt, compat, nshots, dsx = case
+    nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+    rng = np.random.default_rng(nx + nz)
+    vp = (1500 + 2500 * rng.random((nx, nz))).astype(np.float32)
+    srce = (F.ricker_wavelet(nt, 0.001, 30.0) + 0.3).astype(np.float32)
+    d_obs = rng.standard_normal((nshots, nx, nt)).astype(np.float32)
+    sx0 = nxb + (nx // 2 if dsx < 0 else 2)
+    sz, gz = max(nzb, order // 2) + 1, nzb + 1
+    ctx = F.FDWave(order, nxe, nze, nxb, nzb, nt, 0.75, 10.0, 10.0, 0.001, compat=compat)
+    one = F.FDWave(order, nxe, nze, nxb, nzb, nt, 0.75, 10.0, 10.0, 0.001, compat=compat)
+    seed_img = rng.standard_normal((nshots, nx, nz)).astype(np.float32)         # the image is accumulated into, as fdw_shot does
+    if nzb != 1 and nxb != 1:
+        ctx.model_resident(vp), one.model_resident(vp)
+        T, off = ctx.border_draws(), 12345
+        got = ctx.shot_batch(nshots, sx0, dsx, sz, gz, srce, d_obs, draw_offset=off, imloc=seed_img)
+        for b in range(nshots):
+            one.dev_extendvel_linear(off + b * T)
+            want = one.shot_resident(sx0 + b * dsx, sz, gz, srce, d_obs[b], imloc=seed_img[b])
+            assert np.abs(want - seed_img[b]).max() > 0
+            assert_bit_equal(got[b], want, f"device-drawn model, shot {b}")
+    v2_all = ((1500 + 2500 * rng.random((nshots, nxe, nze))) ** 2).astype(np.float32)
+    got = ctx.shot_batch(nshots, sx0, dsx, sz, gz, srce, d_obs, v2_all=v2_all)
+    for b in range(nshots):
+        assert_bit_equal(got[b], one.shot(v2_all[b], sx0 + b * dsx, sz, gz, srce, d_obs[b]), f"host model, shot {b}")
+    assert ctx.shot_batch_max() >= 1
+    with pytest.raises(F.FdwError):
+        ctx.shot_batch(nshots, nxe - 1, 1, sz, gz, srce, d_obs, v2_all=v2_all)  # the later shots' sources leave the grid
