@@ -77,6 +77,7 @@ struct fdw_ctx {
     // random-border model generated on the device (row f4): interior model, one call's draws, jump tables, the extended model
     float *d_vp = nullptr, *d_vpe = nullptr;
     int* d_draws = nullptr;
+    long long draws_cap = 0;
     unsigned* d_jump = nullptr;
     int njump = 0;
     bool model_resident = false, v2_resident = false;
@@ -84,6 +85,8 @@ struct fdw_ctx {
     int nbatch = 1, batch_dsx = 0, batch_cap = 0;
     float* bfld[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float *b_v2 = nullptr, *b_img = nullptr, *b_dobs = nullptr;
+    float* d_raw = nullptr;      // gathers as the caller holds them ([shot][nx][nt]) before the transposition on the device
+    size_t raw_cap = 0;
     int no_fused_back = 0;   // experiments / tests: backward iterations as two launches (source step, receiver step) -- FDW_NO_FUSED_BACK=1
 };
 
@@ -305,7 +308,7 @@ extern "C" void fdw_destroy(fdw_ctx* c)
     float* bufs[] = {c->d_taperz, c->d_txfac, c->d_gcx, c->d_gcz, c->fld[0], c->fld[1], c->fld[2], c->fld[3],
                      c->fld[4], c->fld[5], c->fld[6], c->fld[7], c->d_v2, c->d_img, c->d_srce, c->d_dobs, c->d_rec,
                      c->d_vp, c->d_vpe, (float*)c->d_draws, (float*)c->d_jump, c->bfld[0], c->bfld[1], c->bfld[2], c->bfld[3],
-                     c->bfld[4], c->bfld[5], c->bfld[6], c->bfld[7], c->b_v2, c->b_img, c->b_dobs};
+                     c->bfld[4], c->bfld[5], c->bfld[6], c->bfld[7], c->b_v2, c->b_img, c->b_dobs, c->d_raw};
     for (float* b : bufs)
         if (b) (void)hipFree(b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -853,16 +856,21 @@ extern "C" int fdw_forward(fdw_ctx* c, float* p, float* pp, const float* v2, int
 }
 
 // d_obs [nx][nt] (R:426-435) -> device [nt][nx] so that one step's samples are contiguous
+static int gathers_to_device(fdw_ctx* c, const float* d_obs, float* d_dst, int nshots)
+{
+    const size_t n = (size_t)c->nx * c->prm.nt * nshots;
+    int rc = ensure_cap(&c->d_raw, &c->raw_cap, n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_raw, d_obs, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    hipError_t e = launch_gather_transpose(c->d_raw, d_dst, c->nx, c->prm.nt, nshots, c->stream);
+    if (e != hipSuccess) return fail(FDW_EHIP, "gather transposition launch failed: %s", hipGetErrorString(e));
+    return FDW_OK;
+}
 static int upload_gather(fdw_ctx* c, const float* d_obs)
 {
-    const size_t nx = c->nx, nt = c->prm.nt;
-    int rc = ensure_cap(&c->d_dobs, &c->dobs_cap, nx * nt);
+    int rc = ensure_cap(&c->d_dobs, &c->dobs_cap, (size_t)c->nx * c->prm.nt);
     if (rc) return rc;
-    std::vector<float> t(nx * nt);
-    for (size_t i = 0; i < nx; i++)
-        for (size_t k = 0; k < nt; k++) t[k * nx + i] = d_obs[i * nt + k];
-    HIP_TRY(hipMemcpy(c->d_dobs, t.data(), nx * nt * sizeof(float), hipMemcpyHostToDevice));
-    return FDW_OK;
+    return gathers_to_device(c, d_obs, c->d_dobs, 1);
 }
 
 static int image_to_device(fdw_ctx* c, const float* imloc)
@@ -1343,6 +1351,20 @@ int ensure_rand_tables(fdw_ctx* c, long long ndraws)
 }
 }  // namespace
 
+static int ensure_draws(fdw_ctx* c, long long n)
+{
+    n = std::max<long long>(n, 1);
+    int rc = ensure_rand_tables(c, n);
+    if (rc || c->draws_cap >= n) return rc;
+    if (c->d_draws) (void)hipFree(c->d_draws);
+    c->d_draws = nullptr;
+    c->draws_cap = 0;
+    hipError_t e = hipMalloc((void**)&c->d_draws, (size_t)n * sizeof(int));
+    if (e != hipSuccess) return fail(FDW_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    c->draws_cap = n;
+    return FDW_OK;
+}
+
 extern "C" long long fdw_border_draws(int nx, int nz, int nxb, int nzb)
 {
     if (nx < 0 || nz < 0 || nxb < 0 || nzb < 0) return -1;
@@ -1382,11 +1404,10 @@ extern "C" int fdw_model_resident(fdw_ctx* c, const float* vp)
     const size_t n = (size_t)c->nx * c->nz;
     if (!c->d_vp) {
         hipError_t e = hipMalloc((void**)&c->d_vp, n * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void**)&c->d_draws, (size_t)std::max<long long>(fdw_border_draws(c->nx, c->nz, nxb, nzb), 1) * sizeof(int));
         if (e != hipSuccess) return fail(FDW_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
     }
+    if ((rc = ensure_draws(c, fdw_border_draws(c->nx, c->nz, nxb, nzb)))) return rc;
     if ((rc = alloc_zero(&c->d_vpe, field_elems(c)))) return rc;
-    if ((rc = ensure_rand_tables(c, std::max<long long>(fdw_border_draws(c->nx, c->nz, nxb, nzb), 1)))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_vp, vp, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->model_resident = true;
@@ -1438,7 +1459,7 @@ extern "C" int fdw_shot_batch_max(const fdw_ctx* c)
 {
     if (!c || !is_full_grid(c) || !batch_ok(c)) return 1;
     const long waves = (long)c->nxl * ((c->pitch + 255) / 256);        // one-row-per-wave regime: waves one shot launches
-    const long by_fill = 16384 / std::max<long>(waves, 1);            // ~16 waves per SIMD in flight across the chip
+    const long by_fill = 32768 / std::max<long>(waves, 1);            // measured on new_mod-sized shots: 18.6 ms per shot alone, 5.6 at 8, 4.4 at 16, 3.7 at 32
     const long by_mem = (long)(((size_t)6 << 30) / (11 * field_elems(c) * sizeof(float)));
     return (int)std::max<long>(1, std::min<long>({by_fill, by_mem, 64}));
 }
@@ -1504,25 +1525,21 @@ extern "C" int fdw_shot_batch(fdw_ctx* c, int nshots, const float* v2_all, unsig
     }
     if ((rc = ensure_work_buffers(c, 8, true)) || (rc = ensure_batch_buffers(c, nshots)) || (rc = upload_source(c, srce, nt))) return rc;
     hipStream_t s = c->stream;
-    // gathers [shot][nx][nt] -> [shot][nt][nx]
-    {
-        std::vector<float> t(ng * nshots);
-        for (int b = 0; b < nshots; b++)
-            for (size_t i = 0; i < (size_t)c->nx; i++)
-                for (size_t k = 0; k < (size_t)nt; k++) t[b * ng + k * c->nx + i] = d_obs[b * ng + i * nt + k];
-        HIP_TRY(hipMemcpy(c->b_dobs, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
+    if ((rc = gathers_to_device(c, d_obs, c->b_dobs, nshots))) return rc;      // [shot][nx][nt] -> [shot][nt][nx]
     const long long draws = fdw_border_draws(c->nx, c->nz, c->prm.nxb, c->prm.nzb);
+    if (!v2_all) {      // the shots' draws are consecutive in the stream: one launch generates them all
+        HIP_TRY(hipStreamSynchronize(s));                     // a larger draw buffer replaces one the stream may still be reading
+        if ((rc = ensure_draws(c, draws * nshots))) return rc;
+        hipError_t e = launch_rand_stream(window_at(kGlibcDiscard + draw_offset), c->d_jump, c->njump, draws * nshots, c->d_draws, s);
+        if (e != hipSuccess) return fail(FDW_EHIP, "rand_stream launch failed: %s", hipGetErrorString(e));
+    }
     for (int b = 0; b < nshots; b++) {
         if (v2_all) {
             HIP_TRY(hipMemcpy2DAsync(c->b_v2 + b * fe, (size_t)c->pitch * sizeof(float), v2_all + b * ne, (size_t)c->prm.nze * sizeof(float),
                                      (size_t)c->prm.nze * sizeof(float), c->nxl, hipMemcpyHostToDevice, s));
         } else {
-            hipError_t e = launch_rand_stream(window_at(kGlibcDiscard + draw_offset + (unsigned long long)b * draws), c->d_jump, c->njump, draws, c->d_draws, s);
-            if (e == hipSuccess) {
-                BorderArgs ba{c->d_vp, c->d_draws, nullptr, c->b_v2 + b * fe, c->nx, c->nz, c->prm.nxb, c->prm.nzb, c->pitch};
-                e = launch_extendvel(ba, s);
-            }
+            BorderArgs ba{c->d_vp, c->d_draws + (size_t)b * draws, nullptr, c->b_v2 + b * fe, c->nx, c->nz, c->prm.nxb, c->prm.nzb, c->pitch};
+            hipError_t e = launch_extendvel(ba, s);
             if (e != hipSuccess) return fail(FDW_EHIP, "border model launch failed: %s", hipGetErrorString(e));
         }
     }

@@ -116,7 +116,27 @@ __global__ __launch_bounds__(256) void fdw_extendvel_kernel(BorderArgs a)
     a.vel2[o] = v * v;
 }
 
+// gathers d_obs[shot][nx][nt] (R:426-435) -> [shot][nt][nx], so that one time step's receiver samples are contiguous: 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void fdw_gather_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols)
+{
+    __shared__ float tile[32][33];
+    const size_t shot = (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = in[shot + (size_t)(r0 + j) * cols + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < cols && r0 + tx < rows) out[shot + (size_t)(c0 + j) * rows + r0 + tx] = tile[tx][j];
+}
+
 }  // namespace
+
+hipError_t launch_gather_transpose(const float* d_in, float* d_out, int nx, int nt, int nshots, hipStream_t s)
+{
+    if (nx <= 0 || nt <= 0 || nshots <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fdw_gather_transpose_kernel, dim3((nt + 31) / 32, (nx + 31) / 32, nshots), dim3(256), 0, s, d_in, d_out, nx, nt);
+    return hipGetLastError();
+}
 
 hipError_t launch_rand_stream(const RandWindow& w0, const unsigned* d_jump, int njump, long long n, int* d_out, hipStream_t s)
 {

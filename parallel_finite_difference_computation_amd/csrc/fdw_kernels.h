@@ -120,5 +120,7 @@ struct BorderArgs {
 // d_jump: njump matrices M^(31 2^j), row-major 31x31 each; d_out[i] = draw number i counted from window w0
 hipError_t launch_rand_stream(const RandWindow& w0, const unsigned* d_jump, int njump, long long n, int* d_out, hipStream_t s);
 hipError_t launch_extendvel(const BorderArgs& a, hipStream_t s);
+// d_in [nshots][nx][nt] -> d_out [nshots][nt][nx]
+hipError_t launch_gather_transpose(const float* d_in, float* d_out, int nx, int nt, int nshots, hipStream_t s);
 
 }  // namespace fdw

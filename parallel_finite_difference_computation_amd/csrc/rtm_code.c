@@ -192,8 +192,29 @@ int main(int argc, char **argv)
     if (getenv("FDW_SHOT_WORKERS")) nworkers = atoi(getenv("FDW_SHOT_WORKERS"));
     if (nworkers < 1) nworkers = 1;
     if (nworkers > ns) nworkers = ns;
+    if (nworkers > 64) nworkers = 64;
     while (nworkers > 1 && (size_t)ns * (ne + ni) * sizeof(float) > ((size_t)8 << 30)) nworkers = 1;   /* big decks: one shot fills the GPU anyway */
-    const int batch = nworkers > 1 ? ns : 1;      /* shots whose model and image are held at once */
+    /* Small decks: a whole batch of shots advances through ONE launch per time step (fdw_shot_batch; the library says how many shots fill
+     * the chip for this geometry, 1 = the grid is big enough by itself).  FDW_NO_SHOT_BATCH=1 keeps one shot per launch sequence. */
+    fdw_ctx *bctx = NULL;
+    int bmax = 1;
+    if (dev_border && ns > 1 && !getenv("FDW_NO_SHOT_BATCH")) {
+        if (fdw_create(&prm, 0, &bctx) != FDW_OK) {
+            fprintf(stderr, "fdw_create: %s\n", fdw_last_error());
+            return EXIT_FAILURE;
+        }
+        bmax = fdw_shot_batch_max(bctx);
+        if (bmax > ns) bmax = ns;
+        if (bmax > 1 && fdw_model_resident(bctx, vp) != FDW_OK) {
+            fprintf(stderr, "fdw_model_resident: %s\n", fdw_last_error());
+            return EXIT_FAILURE;
+        }
+        if (bmax <= 1) {
+            fdw_destroy(bctx);
+            bctx = NULL;
+        }
+    }
+    const int batch = bctx ? bmax : (nworkers > 1 ? ns : 1);      /* shots whose model and image are held at once */
     float *vel2_all = (float *)malloc((size_t)batch * ne * sizeof(float)), *imloc_all = (float *)calloc((size_t)batch * ni, sizeof(float));
     if (!vel2_all || !imloc_all) {
         fprintf(stderr, "out of host memory\n");
@@ -219,19 +240,28 @@ int main(int argc, char **argv)
         const double t0 = now_s();
         job.is0 = is0; job.nb = nb;
         memset(imloc_all, 0, (size_t)nb * ni * sizeof(float));                                 /* R:515 */
-        const int nw = nb < nworkers ? nb : nworkers;
-        pthread_t th[64];
-        shot_worker_arg wa[64];
-        for (int w = 0; w < nw; w++) {
-            wa[w].job = &job; wa[w].w = w; wa[w].nw = nw;
-            if (w > 0 && pthread_create(&th[w], NULL, shot_worker, &wa[w]) != 0) {
-                fprintf(stderr, "pthread_create failed\n");
+        if (bctx) {
+            /* shots is0 .. is0 + nb - 1: source rows sx[is0] + b ds (R:405-407), border models from draws [(is0 + b) T, ...) of the stream */
+            if (fdw_shot_batch(bctx, nb, NULL, (unsigned long long)is0 * (unsigned long long)job.draws, sx[is0], ds, sz, gz, srce,
+                               d_obs + (size_t)is0 * nx * nt, imloc_all) != FDW_OK) {
+                fprintf(stderr, "fdw_shot_batch: %s\n", fdw_last_error());
                 return EXIT_FAILURE;
             }
+        } else {
+            const int nw = nb < nworkers ? nb : nworkers;
+            pthread_t th[64];
+            shot_worker_arg wa[64];
+            for (int w = 0; w < nw; w++) {
+                wa[w].job = &job; wa[w].w = w; wa[w].nw = nw;
+                if (w > 0 && pthread_create(&th[w], NULL, shot_worker, &wa[w]) != 0) {
+                    fprintf(stderr, "pthread_create failed\n");
+                    return EXIT_FAILURE;
+                }
+            }
+            shot_worker(&wa[0]);
+            for (int w = 1; w < nw; w++) pthread_join(th[w], NULL);
+            if (job.failed) return EXIT_FAILURE;
         }
-        shot_worker(&wa[0]);
-        for (int w = 1; w < nw; w++) pthread_join(th[w], NULL);
-        if (job.failed) return EXIT_FAILURE;
         const double t1 = now_s();
         t_shots += t1 - t0;
         for (int b = 0; b < nb; b++) {               /* R:480-529 in shot order */
@@ -272,6 +302,7 @@ int main(int argc, char **argv)
     fclose(fimg);
     fclose(fimg_lap);
     fclose(fnum);
+    if (bctx) fdw_destroy(bctx);
     free(srce); free(sx); free(vel_ext_rnd); free(d_obs); free(vp); free(vpe); free(vel2_all);
     free(imloc_all); free(img); free(img_lap);
     fdw_deck_free(deck);

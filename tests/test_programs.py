@@ -147,11 +147,12 @@ def test_rtm_code_program_vs_oracle_pipeline(tmp_path, with_vel_ext):
     assert np.abs(got).max() > 0
     lap = np.fromfile(tmp_path / "output" / "dir.image_lap", np.float32)
     assert lap.size == nx * nz and not lap.any()
-    if not with_vel_ext:  # the border model came from the device generator; the host loop (FDW_HOST_BORDER=1) gives the same file
-        r2 = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=tmp_path, capture_output=True, text=True,
-                            env=dict(os.environ, FDW_HOST_BORDER="1"))
-        assert r2.returncode == 0, r2.stderr
-        assert_bit_equal(np.fromfile(tmp_path / "output" / "dir.image", np.float32).reshape(nx, nz), img, "dir.image, host border loop")
+    if not with_vel_ext:  # that run drew the border models on the device and took the three shots as ONE batch (a launch per time step for all);
+        #                   one shot at a time (FDW_NO_SHOT_BATCH=1) and the host border loop (FDW_HOST_BORDER=1) give the same file
+        for env in ({"FDW_NO_SHOT_BATCH": "1"}, {"FDW_HOST_BORDER": "1"}, {"FDW_NO_SHOT_BATCH": "1", "FDW_SHOT_WORKERS": "1"}):
+            r2 = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=tmp_path, capture_output=True, text=True, env=dict(os.environ, **env))
+            assert r2.returncode == 0, r2.stderr
+            assert_bit_equal(np.fromfile(tmp_path / "output" / "dir.image", np.float32).reshape(nx, nz), img, f"dir.image with {env}")
     if with_vel_ext:      # opt-in deck key: dir.image_lap = the reference's offline Laplacian filter of the stacked image
         (tmp_path / "input.dat").write_text((tmp_path / "input.dat").read_text() + "image_lap=1\n")
         r2 = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=tmp_path, capture_output=True, text=True)
