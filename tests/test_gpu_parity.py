@@ -1069,3 +1069,49 @@ def test_shot_batch_equals_the_shots_one_by_one(case):
     assert ctx.shot_batch_max() >= 1
     with pytest.raises(F.FdwError):
         ctx.shot_batch(nshots, nxe - 1, 1, sz, gz, srce, d_obs, v2_all=v2_all)  # the later shots' sources leave the grid
+
+
+def test_random_shot_batches_property():
+    """Property test: randomly drawn small decks and batch sizes -- fdw_shot_batch equals the shots one by one (which the other tests tie to
+    the oracle), with host-given models; one shot of every batch is also checked against the oracle directly."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+
+    @st.composite
+    def decks(draw):
+        order = draw(st.sampled_from([2, 4, 6, 8, 8, 8]))
+        h = order // 2
+        nxb, nzb = draw(st.integers(0, 16)), draw(st.integers(0, 20))
+        nx, nz = draw(st.integers(max(order + 2, 9), 70)), draw(st.integers(max(order + 2, 9), 330))
+        compat = draw(st.booleans())
+        nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+        xlim = 8 * (nxe // 8) if compat else nxe
+        zlim = 8 * (nze // 8) if compat else nze
+        nshots = draw(st.integers(2, 6))
+        hi = max(nxb, min(nxb + nx - 1, xlim - 1))
+        sx0 = draw(st.integers(nxb, hi))
+        dmax = (hi - sx0) // (nshots - 1)
+        dmin = -((sx0 - nxb) // (nshots - 1))
+        dsx = draw(st.integers(dmin, dmax))
+        sz = draw(st.integers(max(nzb, h), max(max(nzb, h), min(nzb + nz - 1, zlim - 1))))
+        return dict(order=order, nxe=nxe, nze=nze, nxb=nxb, nzb=nzb, nt=draw(st.integers(2, 8)), compat=compat, nshots=nshots, sx0=sx0, dsx=dsx, sz=sz,
+                    gz=draw(st.integers(nzb, nzb + nz - 1)), seed=draw(st.integers(0, 10**6)))
+
+    @settings(max_examples=int(os.environ.get("FDW_PROPERTY_EXAMPLES", "60")), deadline=None, suppress_health_check=list(HealthCheck),
+              derandomize="FDW_PROPERTY_RANDOM" not in os.environ, database=None)
+    @given(decks())
+    def check(c):
+        d = make_deck(c["nxe"], c["nze"], c["nxb"], c["nzb"], c["nt"], seed=c["seed"], order=c["order"], compat=c["compat"])
+        nx, nz, n = c["nxe"] - 2 * c["nxb"], c["nze"] - 2 * c["nzb"], c["nshots"]
+        rng = np.random.default_rng(c["seed"])
+        srce = (O.ricker_wavelet(c["nt"], d["dt"], 30.0) + 0.5).astype(np.float32)
+        d_obs = rng.standard_normal((n, nx, c["nt"])).astype(np.float32)
+        v2_all = np.stack([d["v2"] * np.float32(1.0 + 0.05 * b) for b in range(n)]).astype(np.float32)
+        ctx, one, orc = mk(d), mk(d), mko(d)
+        got = ctx.shot_batch(n, c["sx0"], c["dsx"], c["sz"], c["gz"], srce, d_obs, v2_all=v2_all)
+        for b in range(n):
+            assert_bit_equal(got[b], one.shot(v2_all[b], c["sx0"] + b * c["dsx"], c["sz"], c["gz"], srce, d_obs[b]), f"shot {b} of {c}")
+        b = n - 1
+        oP, oPP = orc.forward(v2_all[b], c["sx0"] + b * c["dsx"], c["sz"], srce)
+        assert_bit_equal(got[b], orc.back(v2_all[b], oP, oPP, d_obs[b], c["gz"]), f"shot {b} vs oracle, {c}")
+
+    check()
