@@ -222,6 +222,9 @@ long long fdw_border_draws(int nx, int nz, int nxb, int nzb);
 int fdw_shot_batch(fdw_ctx *ctx, int nshots, const float *v2_all, unsigned long long draw_offset, int sx0, int dsx, int sz, int gz,
                    const float *srce, const float *d_obs, float *imloc);
 int fdw_shot_batch_max(const fdw_ctx *ctx);
+/* mod_main's shot loop (mod_main.cpp:140-174) for `nshots` consecutive shots (source rows sx0 + b dsx, M:99-101) on its one velocity
+ * model, one launch per time step for all of them; data[nshots][nx][nt].  Same results as fdw_model_shot per shot, bit for bit. */
+int fdw_model_shot_batch(fdw_ctx *ctx, int nshots, const float *vel2, int sx0, int dsx, int sz, int gz, const float *srce, int nt, float *data);
 int fdw_model_resident(fdw_ctx *ctx, const float *vp);
 int fdw_dev_extendvel_linear(fdw_ctx *ctx, unsigned long long draw_offset, float *vel_out);
 int fdw_shot_resident(fdw_ctx *ctx, int sx, int sz, int gz, const float *srce, const float *d_obs, float *imloc, float *P, float *PP);

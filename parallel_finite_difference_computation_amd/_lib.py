@@ -60,6 +60,7 @@ SIGNATURES = [
     ("fdw_shot_resident", C.c_int, [vp, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, vp, vp]),
     ("fdw_shot_batch", C.c_int, [vp, C.c_int, vp, C.c_ulonglong, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p]),
     ("fdw_shot_batch_max", C.c_int, [vp]),
+    ("fdw_model_shot_batch", C.c_int, [vp, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p]),
     ("fdw_rand_stream", C.c_int, [vp, C.c_ulonglong, C.c_longlong, vp]),
     ("fdw_dev_model_steps", C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
     ("fdw_mod_extendvel", None, [C.c_int] * 4 + [f32p]),

@@ -235,6 +235,13 @@ class FDWave:
         check(lib().fdw_model_shot(self._h, _f32(vel2, (self.nxe, self.nze)), sx, sz, gz, srce, srce.size, data))
         return data
 
+    def model_shot_batch(self, nshots, vel2, sx0, dsx, sz, gz, srce):
+        """`nshots` consecutive shots of mod_main's loop through one launch per time step: data[nshots][nx][nt]."""
+        srce = _f32(srce)
+        data = np.zeros((nshots, self.nx, srce.size), np.float32)
+        check(lib().fdw_model_shot_batch(self._h, nshots, _f32(vel2, (self.nxe, self.nze)), sx0, dsx, sz, gz, srce, srce.size, data))
+        return data
+
     def rtm_stored_shot(self, vel2, sx, sz, gz, srce, dobs, shot=0):
         """One shot of the sibling's stored-wavefield RTM (dpct_gpu_rtm_domain_division/src/rtm_main.cpp:158-240); dobs is the WHOLE
         gather [ns][nx][nt] (the reference reads one sample past each trace, see fdwave.h).  Returns imloc[nx][nz]."""

@@ -82,7 +82,7 @@ struct fdw_ctx {
     int njump = 0;
     bool model_resident = false, v2_resident = false;
     // a batch of shots through one launch per time step (fdw_shot_batch): per-shot copies of the eight fields, v2, image, gather
-    int nbatch = 1, batch_dsx = 0, batch_cap = 0;
+    int nbatch = 1, batch_dsx = 0, batch_cap = 0, batch_nt = 0;
     float* bfld[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float *b_v2 = nullptr, *b_img = nullptr, *b_dobs = nullptr;
     float* d_raw = nullptr;      // gathers as the caller holds them ([shot][nx][nt]) before the transposition on the device
@@ -424,8 +424,11 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
     if (c->nbatch > 1) {      // fdw_shot_batch: shot b = these pointers + b fields, its own gather, its own source row
         a.nbatch = c->nbatch;
         a.bstride = (long long)field_elems(c);
-        a.inj_bstride = mode == FDW_MODE_FWD ? 0 : (long long)c->nx * c->prm.nt;
-        a.inj_dx = mode == FDW_MODE_FWD ? c->batch_dsx : 0;
+        const bool one_source = mode == FDW_MODE_FWD || mode == FDW_MODE_MOD;     // the wavelet is shared, its row moves; receivers: a gather each
+        a.inj_bstride = one_source ? 0 : (long long)c->nx * c->prm.nt;
+        a.inj_dx = one_source ? c->batch_dsx : 0;
+        a.v2_bstride = mode == FDW_MODE_MOD ? 0 : a.bstride;                       // mod_main models every shot on one velocity model (M:140-174)
+        a.rec_bstride = (long long)c->nx * c->batch_nt;
     }
     hipError_t e;
     if (c->h <= kMaxFastHalfOrder && !c->use_generic) {
@@ -1451,6 +1454,7 @@ extern "C" int fdw_shot_resident(fdw_ctx* c, int sx, int sz, int gz, const float
 // shot * field, the gather by shot * nx * nt, the source row by shot * dsx (the reference's sx = fsx + is * ds, R:405-407).
 static bool batch_ok(const fdw_ctx* c)
 {
+    if (c->prm.dialect == FDW_DIALECT_MOD) return c->h <= kMaxFastHalfOrder && !c->use_generic && !pipe_pays(c);
     return c->prm.dialect == FDW_DIALECT_RTM && c->h <= kMaxFastHalfOrder && !c->use_generic && !c->no_fused_back && !two_step_pays(c) &&
            !pipe_pays(c) && c->prm.nxb + c->nx <= c->upd_x1 /* no receiver rows outside the time-stepped extent */;
 }
@@ -1488,7 +1492,7 @@ static int ensure_batch_buffers(fdw_ctx* c, int n)
 namespace {
 struct BatchScope {      // the context's single-shot buffers step aside for the batch ones while a batch runs
     fdw_ctx* c;
-    explicit BatchScope(fdw_ctx* ctx, int n, int dsx) : c(ctx) { swap(); c->nbatch = n; c->batch_dsx = dsx; }
+    explicit BatchScope(fdw_ctx* ctx, int n, int dsx) : c(ctx) { swap(); c->nbatch = n; c->batch_dsx = dsx; c->batch_nt = c->prm.nt; }
     ~BatchScope() { swap(); c->nbatch = 1; c->batch_dsx = 0; }
     void swap()
     {
@@ -1564,6 +1568,43 @@ extern "C" int fdw_shot_batch(fdw_ctx* c, int nshots, const float* v2_all, unsig
     for (int b = 0; b < nshots; b++)
         HIP_TRY(hipMemcpy2DAsync(imloc + b * ni, (size_t)c->nz * sizeof(float), c->b_img + b * fe + (size_t)c->prm.nxb * c->pitch + c->prm.nzb,
                                  (size_t)c->pitch * sizeof(float), (size_t)c->nz * sizeof(float), c->nx, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return FDW_OK;
+}
+
+// mod_main's shot loop (M:140-174) for `nshots` consecutive shots on its one velocity model, one launch per time step for all of them
+extern "C" int fdw_model_shot_batch(fdw_ctx* c, int nshots, const float* vel2, int sx0, int dsx, int sz, int gz, const float* srce, int nt, float* data)
+{
+    if (!c || !vel2 || !data || (!srce && nt > 0)) return fail(FDW_EINVAL, "NULL argument");
+    if (c->prm.dialect != FDW_DIALECT_MOD) return fail(FDW_ESTATE, "fdw_model_shot_batch needs a context created with dialect = FDW_DIALECT_MOD");
+    if (!is_full_grid(c)) return fail(FDW_EINVAL, "fdw_model_shot_batch needs a full-grid context");
+    if (nshots < 1 || nt < 0) return fail(FDW_EINVAL, "nshots=%d nt=%d", nshots, nt);
+    if (gz < c->prm.nzb || gz >= c->prm.nzb + c->nz)
+        return fail(FDW_EINVAL, "receiver depth %d is not an interior column [%d,%d)", gz, c->prm.nzb, c->prm.nzb + c->nz);
+    const int sx_last = sx0 + (nshots - 1) * dsx;
+    if (std::min(sx0, sx_last) < 0 || std::max(sx0, sx_last) >= c->prm.nxe) return fail(FDW_EINVAL, "source rows %d..%d leave the grid", sx0, sx_last);
+    const size_t nx = c->nx, ng = nx * (size_t)nt, fe = field_elems(c);
+    int rc;
+    if (nshots == 1 || nt == 0 || nt > c->prm.nt || !batch_ok(c)) {
+        for (int b = 0; b < nshots; b++)
+            if ((rc = fdw_model_shot(c, vel2, sx0 + b * dsx, sz, gz, srce, nt, data + b * ng))) return rc;
+        return FDW_OK;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = ensure_work_buffers(c, 2, false)) || (rc = ensure_batch_buffers(c, nshots)) || (rc = upload_source(c, srce, nt))) return rc;
+    if ((rc = ensure_cap(&c->d_raw, &c->raw_cap, ng * nshots))) return rc;
+    hipStream_t s = c->stream;
+    if ((rc = upload_rows(c, c->d_v2, vel2, s))) return rc;
+    HIP_TRY(hipMemsetAsync(c->bfld[0], 0, fe * nshots * sizeof(float), s));   // M:144-145
+    HIP_TRY(hipMemsetAsync(c->bfld[1], 0, fe * nshots * sizeof(float), s));
+    c->nbatch = nshots; c->batch_dsx = dsx; c->batch_nt = nt;
+    rc = fdw_dev_model_steps(c, c->bfld[0], c->bfld[1], c->d_v2, c->d_srce, sx0, sz, gz, c->b_dobs, 0, nt, s);
+    c->nbatch = 1; c->batch_dsx = 0;
+    if (rc) return rc;
+    // device [shot][it][ix] -> data[shot][ix][it] (M:156)
+    hipError_t e = launch_gather_transpose(c->b_dobs, c->d_raw, nt, (int)nx, nshots, s);
+    if (e != hipSuccess) return fail(FDW_EHIP, "gather transposition launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(data, c->d_raw, ng * nshots * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return FDW_OK;
 }

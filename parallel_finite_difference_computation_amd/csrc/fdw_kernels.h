@@ -51,7 +51,8 @@ struct StepArgs {
     int rec_z, rec_x0, rec_n;
     // batch of independent shots on one geometry (gridDim.y = shots; 0 / 1 = a single shot): shot b works on field pointers + b * bstride,
     // samples inj + b * inj_bstride, source row inj_x + b * inj_dx
-    long long bstride, inj_bstride;
+    // (v2 + b * v2_bstride: one model per shot in the RTM loop, one for all in the modelling loop; rec + b * rec_bstride)
+    long long bstride, inj_bstride, v2_bstride, rec_bstride;
     int inj_dx, nbatch;
 };
 

@@ -35,6 +35,7 @@ struct ShotView {
     float* img;
     const float* inj;
     int inj_x;
+    float* rec;
 };
 
 template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false, bool BACK = false>
@@ -207,7 +208,7 @@ __device__ __forceinline__ void march(const StepArgs& a, const ShotView& sv, con
                 if (rec_here && r >= a.rec_x0 && r < a.rec_x0 + a.rec_n) {      // the trace sample of this step: the current field at depth rec_z
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (z0 + e == a.rec_z) a.rec[r - a.rec_x0] = c.v[e];      // interior point: its damping factors are 1.0f
+                        if (z0 + e == a.rec_z) sv.rec[r - a.rec_x0] = c.v[e];      // interior point: its damping factors are 1.0f
                 }
                 float W[12];
 #pragma unroll
@@ -355,7 +356,8 @@ __global__ __launch_bounds__(256) void fdw_step_kernel(const StepArgs a)
     // a batch of independent shots of one geometry fills the chip where one small grid cannot: blockIdx.y picks the shot
     const int shot = blockIdx.y;
     const long long o = shot * a.bstride;
-    const ShotView sv{a.p + o, a.pp + o, a.v2 + o, a.psrc + o, a.fpp + o, a.img + o, a.inj + shot * a.inj_bstride, a.inj_x + shot * a.inj_dx};
+    const ShotView sv{a.p + o, a.pp + o, a.v2 + shot * a.v2_bstride, a.psrc + o, a.fpp + o, a.img + o, a.inj + shot * a.inj_bstride,
+                      a.inj_x + shot * a.inj_dx, a.rec + shot * a.rec_bstride};
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 

@@ -2,7 +2,7 @@
  * (dpct_gpu_rtm_domain_division/src/mod_main.cpp = M):
  *     ./mod_main par=input.dat          (the SU getpar form its run scripts use; a bare file name works too)
  * Same deck keys and defaults (M:63-86), same input (vpfile [nx][nz]), same output: `datfile` = data[ns][nx][nt] float32, the
- * gather an RTM run reads back as its datfile.  Per shot the whole loop M:140-174 is one device-resident fdw_model_shot() call.
+ * gather an RTM run reads back as its datfile.  The whole loop M:140-174 of a batch of shots is one device-resident fdw_model_shot_batch() call.
  * Not reproduced: the "* it = ..." progress lines every 100 steps. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -91,11 +91,14 @@ int main(int argc, char **argv)
         return EXIT_FAILURE;
     }
     float *data = (float *)calloc((size_t)ns * nx * nt, sizeof(float));
-    for (int is = 0; is < ns; is++) {
-        const int sx = fsx + is * ds + nxb;                 /* M:99-101 */
-        printf("** source %d, at (%d,%d) \n", is + 1, sx - nxb, sz - nzb);
-        if (fdw_model_shot(ctx, vel2, sx, sz, gz, srce, nt, data + (size_t)is * nx * nt) != FDW_OK) {
-            fprintf(stderr, "fdw_model_shot: %s\n", fdw_last_error());
+    /* small decks: a batch of shots per launch (fdw_shot_batch_max says how many fill the chip; 1 = the grid is big enough alone) */
+    int bmax = getenv("FDW_NO_SHOT_BATCH") ? 1 : fdw_shot_batch_max(ctx);
+    if (bmax < 1) bmax = 1;
+    for (int is0 = 0; is0 < ns; is0 += bmax) {
+        const int nb = is0 + bmax <= ns ? bmax : ns - is0;
+        for (int is = is0; is < is0 + nb; is++) printf("** source %d, at (%d,%d) \n", is + 1, fsx + is * ds, sz - nzb); /* M:99-101 */
+        if (fdw_model_shot_batch(ctx, nb, vel2, fsx + is0 * ds + nxb, ds, sz, gz, srce, nt, data + (size_t)is0 * nx * nt) != FDW_OK) {
+            fprintf(stderr, "fdw_model_shot_batch: %s\n", fdw_last_error());
             return EXIT_FAILURE;
         }
     }

@@ -1115,3 +1115,30 @@ def test_random_shot_batches_property():
         assert_bit_equal(got[b], orc.back(v2_all[b], oP, oPP, d_obs[b], c["gz"]), f"shot {b} vs oracle, {c}")
 
     check()
+
+
+@pytest.mark.parametrize("case", [(8, 61, 47, 17, 13, 40, 5, 7), (8, 40, 300, 5, 30, 20, 3, -4), (4, 50, 44, 6, 7, 30, 4, 0), (8, 33, 35, 0, 0, 16, 6, 5)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_model_shot_batch_equals_the_shots_one_by_one(case):
+    """fdw_model_shot_batch (mod_main's shot loop, one launch per time step for all shots of the batch, one velocity model) against
+    fdw_model_shot per shot and, for the last shot, the oracle: bit for bit; also a trace shorter than the context's nt."""
+    order, nx, nz, nxb, nzb, nt, nshots, dsx = case
+    nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+    rng = np.random.default_rng(nx * 3 + nz)
+    vp = (1500 + 2500 * rng.random((nx, nz))).astype(np.float32)
+    v2 = np.zeros((nxe, nze), np.float32)
+    v2[nxb:nxb + nx, nzb:nzb + nz] = vp * vp
+    v2 = F.mod_extendvel(v2, nx, nz, nxb, nzb)
+    srce = (F.mod_ricker_wavelet(nt, 0.001, 40.0) + 0.1 * rng.standard_normal(nt)).astype(np.float32)
+    sx0, sz, gz = nxb + (nx - 2 if dsx < 0 else 1), nzb + 2, nzb + 1
+    ctx = F.FDWave(order, nxe, nze, nxb, nzb, nt, 0.02, 10.0, 12.5, 0.001, dialect=1)
+    one = F.FDWave(order, nxe, nze, nxb, nzb, nt, 0.02, 10.0, 12.5, 0.001, dialect=1)
+    assert ctx.shot_batch_max() > 1
+    for n in (nt, nt - 3):
+        got = ctx.model_shot_batch(nshots, v2, sx0, dsx, sz, gz, srce[:n])
+        for b in range(nshots):
+            want = one.model_shot(v2, sx0 + b * dsx, sz, gz, srce[:n])
+            assert np.abs(want).max() > 0
+            assert_bit_equal(got[b], want, f"shot {b}, nt {n}")
+    b = nshots - 1
+    assert_bit_equal(got[b], O.mod_shot(order, nx, nz, nxb, nzb, 10.0, 12.5, 0.001, 0.02, v2, sx0 + b * dsx, sz, gz, srce[:nt - 3]), "vs oracle")
