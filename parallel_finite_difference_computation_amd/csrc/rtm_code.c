@@ -198,14 +198,14 @@ int main(int argc, char **argv)
      * the chip for this geometry, 1 = the grid is big enough by itself).  FDW_NO_SHOT_BATCH=1 keeps one shot per launch sequence. */
     fdw_ctx *bctx = NULL;
     int bmax = 1;
-    if (dev_border && ns > 1 && !getenv("FDW_NO_SHOT_BATCH")) {
+    if (ns > 1 && !getenv("FDW_NO_SHOT_BATCH")) {
         if (fdw_create(&prm, 0, &bctx) != FDW_OK) {
             fprintf(stderr, "fdw_create: %s\n", fdw_last_error());
             return EXIT_FAILURE;
         }
         bmax = fdw_shot_batch_max(bctx);
         if (bmax > ns) bmax = ns;
-        if (bmax > 1 && fdw_model_resident(bctx, vp) != FDW_OK) {
+        if (bmax > 1 && dev_border && fdw_model_resident(bctx, vp) != FDW_OK) {
             fprintf(stderr, "fdw_model_resident: %s\n", fdw_last_error());
             return EXIT_FAILURE;
         }
@@ -242,7 +242,8 @@ int main(int argc, char **argv)
         memset(imloc_all, 0, (size_t)nb * ni * sizeof(float));                                 /* R:515 */
         if (bctx) {
             /* shots is0 .. is0 + nb - 1: source rows sx[is0] + b ds (R:405-407), border models from draws [(is0 + b) T, ...) of the stream */
-            if (fdw_shot_batch(bctx, nb, NULL, (unsigned long long)is0 * (unsigned long long)job.draws, sx[is0], ds, sz, gz, srce,
+            /* models: drawn on the device, or the host-built ones of this batch (vel_ext_file decks, FDW_HOST_BORDER=1) */
+            if (fdw_shot_batch(bctx, nb, dev_border ? NULL : vel2_all, (unsigned long long)is0 * (unsigned long long)job.draws, sx[is0], ds, sz, gz, srce,
                                d_obs + (size_t)is0 * nx * nt, imloc_all) != FDW_OK) {
                 fprintf(stderr, "fdw_shot_batch: %s\n", fdw_last_error());
                 return EXIT_FAILURE;

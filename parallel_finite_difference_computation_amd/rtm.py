@@ -114,19 +114,21 @@ def run(deck_path, out=sys.stdout):
     # Small decks: a contiguous block of shots per rank, advanced in batches through ONE launch per time step (fdw_shot_batch: the shots of
     # a batch need consecutive places in the rand() stream and equally spaced sources, which consecutive shots have, fd-code.cu:405-407)
     batched = False
-    if dev_border and "FDW_NO_SHOT_BATCH" not in os.environ:
+    if (dev_border or vel_ext is not None) and "FDW_NO_SHOT_BATCH" not in os.environ:
         ctx = api.FDWave(d["order"], nxe, nze, nxb, nzb, nt, d["fac"], d["dx"], d["dz"], d["dt"], compat=True, device=local)
         B = ctx.shot_batch_max()
         if B > 1:
             batched = True
-            ctx.model_resident(vp)
+            if dev_border:
+                ctx.model_resident(vp)
             T = ctx.border_draws()
             lo, hi = rank * ns // world, (rank + 1) * ns // world
             for s0 in range(lo, hi, B):
                 nb = min(B, hi - s0)
                 for s in range(s0, s0 + nb):
                     print(f"** source {s + 1}, at ({sx[s] - nxb},{sz - nzb}) " + (f" [rank {rank}]" if world > 1 else ""), file=out, flush=True)
-                imgs = ctx.shot_batch(nb, sx[s0], d["ds"], sz, gz, srce, np.ascontiguousarray(d_obs[s0:s0 + nb]), draw_offset=s0 * T)
+                v2_all = None if dev_border else np.square(np.asarray(vel_ext[s0:s0 + nb]), dtype=np.float32)    # fd-code.cu:484, 490-494
+                imgs = ctx.shot_batch(nb, sx[s0], d["ds"], sz, gz, srce, np.ascontiguousarray(d_obs[s0:s0 + nb]), v2_all=v2_all, draw_offset=s0 * T)
                 for b in range(nb):
                     mine[s0 + b] = imgs[b]
     with concurrent.futures.ThreadPoolExecutor(max_workers=nworkers) as pool:

@@ -153,6 +153,11 @@ def test_rtm_code_program_vs_oracle_pipeline(tmp_path, with_vel_ext):
             r2 = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=tmp_path, capture_output=True, text=True, env=dict(os.environ, **env))
             assert r2.returncode == 0, r2.stderr
             assert_bit_equal(np.fromfile(tmp_path / "output" / "dir.image", np.float32).reshape(nx, nz), img, f"dir.image with {env}")
+    if with_vel_ext:      # that run took the three shots as one batch on the host-given models; one shot at a time gives the same file
+        r2 = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=tmp_path, capture_output=True, text=True,
+                            env=dict(os.environ, FDW_NO_SHOT_BATCH="1"))
+        assert r2.returncode == 0, r2.stderr
+        assert_bit_equal(np.fromfile(tmp_path / "output" / "dir.image", np.float32).reshape(nx, nz), img, "dir.image, one shot at a time")
     if with_vel_ext:      # opt-in deck key: dir.image_lap = the reference's offline Laplacian filter of the stacked image
         (tmp_path / "input.dat").write_text((tmp_path / "input.dat").read_text() + "image_lap=1\n")
         r2 = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=tmp_path, capture_output=True, text=True)
