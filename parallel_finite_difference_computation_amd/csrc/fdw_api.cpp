@@ -78,7 +78,7 @@ struct fdw_ctx {
     float *d_vp = nullptr, *d_vpe = nullptr;
     int* d_draws = nullptr;
     long long draws_cap = 0;
-    unsigned* d_jump = nullptr;
+    unsigned* d_jump = nullptr;   // the generator's jump table (fdw_border.hip), sized for njump blocks of 64 threads
     int njump = 0;
     bool model_resident = false, v2_resident = false;
     // a batch of shots through one launch per time step (fdw_shot_batch): per-shot copies of the eight fields, v2, image, gather
@@ -1276,7 +1276,7 @@ Mat mat_mul(const Mat& a, const Mat& b)
 
 struct RandTables {
     Mat pow2[64];        // M^(2^j): one stream position per application
-    Mat jump31[40];      // M^(31 2^j): one ring turn per application
+    unsigned glo[65][L]; // x^(31 l) mod P, l = 0..64, P = x^31 - x^28 - 1 (the generator's characteristic polynomial)
     unsigned w0[L];      // window before the first step of a seed-1 generator (before glibc's 310 discarded outputs)
 };
 
@@ -1292,10 +1292,19 @@ const RandTables& rand_tables()
         m[(size_t)(L - 1) * L + 28] = 1;
         t.pow2[0] = m;
         for (int j = 1; j < 64; j++) t.pow2[j] = mat_mul(t.pow2[j - 1], t.pow2[j - 1]);
-        Mat m31 = t.pow2[0];                                  // 31 = 1 + 2 + 4 + 8 + 16
-        for (int j = 1; j < 5; j++) m31 = mat_mul(t.pow2[j], m31);
-        t.jump31[0] = m31;
-        for (int j = 1; j < 40; j++) t.jump31[j] = mat_mul(t.jump31[j - 1], t.jump31[j - 1]);
+        std::memset(t.glo, 0, sizeof t.glo);
+        t.glo[0][0] = 1u;
+        for (int l = 0; l < 64; l++) {
+            unsigned g[L];
+            std::memcpy(g, t.glo[l], sizeof g);
+            for (int k = 0; k < L; k++) {                      // times x: the x^31 term folds into x^28 + 1
+                const unsigned top = g[L - 1];
+                for (int i = L - 1; i > 0; i--) g[i] = g[i - 1];
+                g[0] = top;
+                g[28] += top;
+            }
+            std::memcpy(t.glo[l + 1], g, sizeof g);
+        }
         // glibc srandom_r(1): r[0] = seed, r[i] = 16807 r[i-1] mod (2^31 - 1) by Schrage's method; front pointer at r[3], rear at r[0]
         unsigned r[L];
         int word = 1;
@@ -1335,17 +1344,44 @@ fdw::RandWindow window_at(unsigned long long k)
 
 constexpr unsigned long long kGlibcDiscard = 310;     // outputs srandom_r() throws away
 
+// a * b mod P
+void poly_mul(const unsigned* a, const unsigned* b, unsigned* out)
+{
+    unsigned c[2 * L - 1] = {0};
+    for (int i = 0; i < L; i++)
+        for (int j = 0; j < L; j++) c[i + j] += a[i] * b[j];
+    for (int k = 2 * L - 2; k >= L; k--) {                    // x^k = x^(k-3) + x^(k-31)
+        c[k - 3] += c[k];
+        c[k - L] += c[k];
+    }
+    std::memcpy(out, c, L * sizeof(unsigned));
+}
+
+fdw::RandBase base_at(unsigned long long k)
+{
+    const fdw::RandWindow w = window_at(k);
+    fdw::RandBase b;
+    std::memcpy(b.y, w.w, sizeof w.w);
+    for (int s = 0; s < L - 1; s++) b.y[L + s] = b.y[s] + b.y[s + 28];     // y[K+s] = y[K+s-31] + y[K+s-3]
+    return b;
+}
+
+// device table for up to ndraws draws per launch: [31][64] lane factors, then one block factor per 64 threads
 int ensure_rand_tables(fdw_ctx* c, long long ndraws)
 {
-    int need = 1;
-    while (((ndraws + L - 1) / L) >> need) need++;
-    if (need > 40) return fail(FDW_EINVAL, "%lld draws in one call", ndraws);
+    const long long threads = (ndraws + L - 1) / L;
+    const int need = (int)std::max<long long>((threads + 63) / 64, 1);
     if (c->d_jump && c->njump >= need) return FDW_OK;
     if (c->d_jump) (void)hipFree(c->d_jump);
     c->d_jump = nullptr;
     const RandTables& t = rand_tables();
-    std::vector<unsigned> flat((size_t)need * L * L);
-    for (int j = 0; j < need; j++) std::memcpy(&flat[(size_t)j * L * L], t.jump31[j].data(), (size_t)L * L * sizeof(unsigned));
+    std::vector<unsigned> flat((size_t)L * 64 + (size_t)need * L);
+    for (int i = 0; i < L; i++)
+        for (int l = 0; l < 64; l++) flat[(size_t)i * 64 + l] = t.glo[l][i];
+    unsigned* hi = &flat[(size_t)L * 64];
+    std::memset(hi, 0, L * sizeof(unsigned));
+    hi[0] = 1u;
+    for (int h = 1; h < need; h++) poly_mul(hi + (size_t)(h - 1) * L, t.glo[64], hi + (size_t)h * L);
     hipError_t e = hipMalloc((void**)&c->d_jump, flat.size() * sizeof(unsigned));
     if (e != hipSuccess) return fail(FDW_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
     HIP_TRY(hipMemcpy(c->d_jump, flat.data(), flat.size() * sizeof(unsigned), hipMemcpyHostToDevice));
@@ -1384,7 +1420,7 @@ extern "C" int fdw_rand_stream(fdw_ctx* c, unsigned long long draw_offset, long 
     int* d = nullptr;
     hipError_t e = hipMalloc((void**)&d, (size_t)n * sizeof(int));
     if (e != hipSuccess) return fail(FDW_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
-    e = launch_rand_stream(window_at(kGlibcDiscard + draw_offset), c->d_jump, c->njump, n, d, c->stream);
+    e = launch_rand_stream(base_at(kGlibcDiscard + draw_offset), c->d_jump, n, d, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
@@ -1424,7 +1460,7 @@ extern "C" int fdw_dev_extendvel_linear(fdw_ctx* c, unsigned long long draw_offs
     if (!c->model_resident) return fail(FDW_ESTATE, "no resident model: call fdw_model_resident first");
     HIP_TRY(hipSetDevice(c->device));
     const long long n = fdw_border_draws(c->nx, c->nz, c->prm.nxb, c->prm.nzb);
-    hipError_t e = launch_rand_stream(window_at(kGlibcDiscard + draw_offset), c->d_jump, c->njump, n, c->d_draws, c->stream);
+    hipError_t e = launch_rand_stream(base_at(kGlibcDiscard + draw_offset), c->d_jump, n, c->d_draws, c->stream);
     if (e != hipSuccess) return fail(FDW_EHIP, "rand_stream launch failed: %s", hipGetErrorString(e));
     BorderArgs a{c->d_vp, c->d_draws, c->d_vpe, c->d_v2, c->nx, c->nz, c->prm.nxb, c->prm.nzb, c->pitch};
     e = launch_extendvel(a, c->stream);
@@ -1534,7 +1570,7 @@ extern "C" int fdw_shot_batch(fdw_ctx* c, int nshots, const float* v2_all, unsig
     if (!v2_all) {      // the shots' draws are consecutive in the stream: one launch generates them all
         HIP_TRY(hipStreamSynchronize(s));                     // a larger draw buffer replaces one the stream may still be reading
         if ((rc = ensure_draws(c, draws * nshots))) return rc;
-        hipError_t e = launch_rand_stream(window_at(kGlibcDiscard + draw_offset), c->d_jump, c->njump, draws * nshots, c->d_draws, s);
+        hipError_t e = launch_rand_stream(base_at(kGlibcDiscard + draw_offset), c->d_jump, draws * nshots, c->d_draws, s);
         if (e != hipSuccess) return fail(FDW_EHIP, "rand_stream launch failed: %s", hipGetErrorString(e));
     }
     for (int b = 0; b < nshots; b++) {

@@ -4,8 +4,8 @@
 // The reference draws its border from ONE sequential glibc rand() stream, never seeded, consumed in a fixed loop order (fdw_host.c keeps
 // that order for the host array).  Two facts make it a data-parallel job:
 //   * the generator is glibc's TYPE_3 additive feedback  y[t] = y[t-31] + y[t-3]  over 32-bit words, a LINEAR recurrence: the window
-//     W_K = (y[K-31] .. y[K-1]) is  M^K W_0  for one fixed 31x31 matrix M over Z/2^32, so any thread can jump to its own place in the
-//     stream with a few matrix-vector products (tables of M^(31 2^j), built once on the host by repeated squaring) and then run the
+//     with g = x^K mod (x^31 - x^28 - 1) over Z/2^32,  y[K + s] = sum_i g_i y[i + s]  for every s, so any thread can jump to its own place
+//     in the stream with two 31 x 31 products (small tables of x^(31 l) and x^(31 64 h), built once on the host) and then run the
 //     recurrence for one ring turn of 31 draws;
 //   * which draw a border cell receives, and whether a later phase of the reference's loops overwrites it, is a closed form of its
 //     coordinates (the phases below), so the fill is one thread per cell with no ordering between cells.
@@ -28,30 +28,38 @@ __device__ __forceinline__ void unroll(F&& f)
     }
 }
 
-// thread t: draws [31 t, 31 t + 31) of the n asked for, counted from the window `w0` (= the stream position of draw 0)
-__global__ __launch_bounds__(64) void fdw_rand_stream_kernel(RandWindow w0, const unsigned* __restrict__ jump, int njump, long long n, int* __restrict__ out)
+// thread t = 64 h + l: draws [31 t, 31 t + 31) of the n asked for.  x^(31 t) = x^(31 l) * x^(31 64 h) mod P: one polynomial product (the block's
+// factor is wave-uniform: scalar loads), reduced through x^k = x^(k-3) + x^(k-31), gives g with  y[31 t + s] = sum_i g_i y[i + s]  for every s --
+// a second 31 x 31 product against the base words yields the thread's window, then the recurrence runs one ring turn in registers.
+__global__ __launch_bounds__(64) void fdw_rand_stream_kernel(RandBase base, const unsigned* __restrict__ tab, long long n, int* __restrict__ out)
 {
-    const long long t = (long long)blockIdx.x * 64 + threadIdx.x;
+    const int lane = threadIdx.x;
+    const long long t = (long long)blockIdx.x * 64 + lane;
     if (t * kRandLag >= n) return;
+    const unsigned* hi = tab + kRandLag * 64 + (size_t)blockIdx.x * kRandLag;
+    unsigned a[kRandLag], c[2 * kRandLag - 1];
+    unroll<0, kRandLag>([&](auto i) { a[i] = tab[i * 64 + lane]; });
+    unroll<0, 2 * kRandLag - 1>([&](auto k) { c[k] = 0; });
+    unroll<0, kRandLag>([&](auto j) {
+        const unsigned b = hi[j];
+        unroll<0, kRandLag>([&](auto i) { c[i + j] += a[i] * b; });
+    });
+    unroll<0, kRandLag - 1>([&](auto d) {
+        constexpr int k = 2 * kRandLag - 2 - d;      // 60 .. 31
+        c[k - 3] += c[k];
+        c[k - kRandLag] += c[k];
+    });
     unsigned w[kRandLag];
-    unroll<0, kRandLag>([&](auto s) { w[s] = w0.w[s]; });
-    // jump by 31 t = sum of 31 2^j over the set bits of t; every thread of the launch walks the same tables (scalar loads)
-    for (int j = 0; j < njump; j++) {
-        const unsigned* m = jump + (size_t)j * kRandLag * kRandLag;
-        const bool take = (t >> j) & 1;
-        unsigned v[kRandLag];
-        unroll<0, kRandLag>([&](auto r) {
-            unsigned acc = 0;
-            unroll<0, kRandLag>([&](auto c) { acc += m[r * kRandLag + c] * w[c]; });
-            v[r] = acc;
-        });
-        unroll<0, kRandLag>([&](auto s) { w[s] = take ? v[s] : w[s]; });
-    }
+    unroll<0, kRandLag>([&](auto m) {
+        unsigned acc = 0;
+        unroll<0, kRandLag>([&](auto i) { acc += c[i] * base.y[i + m]; });
+        w[m] = acc;
+    });
     // one ring turn: slot s holds y[K-31+s]; y[K+s] = y[K+s-31] + y[K+s-3], and slot (s+28) mod 31 holds y[K+s-3] by then
-    const long long base = t * kRandLag;
+    const long long first = t * kRandLag;
     unroll<0, kRandLag>([&](auto s) {
         w[s] += w[(s + 28) % kRandLag];
-        if (base + s < n) out[base + s] = (int)(w[s] >> 1);
+        if (first + s < n) out[first + s] = (int)(w[s] >> 1);
     });
 }
 
@@ -138,11 +146,11 @@ hipError_t launch_gather_transpose(const float* d_in, float* d_out, int nx, int 
     return hipGetLastError();
 }
 
-hipError_t launch_rand_stream(const RandWindow& w0, const unsigned* d_jump, int njump, long long n, int* d_out, hipStream_t s)
+hipError_t launch_rand_stream(const RandBase& base, const unsigned* d_tab, long long n, int* d_out, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
     const long long threads = (n + kRandLag - 1) / kRandLag;
-    hipLaunchKernelGGL(fdw_rand_stream_kernel, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, s, w0, d_jump, njump, n, d_out);
+    hipLaunchKernelGGL(fdw_rand_stream_kernel, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, s, base, d_tab, n, d_out);
     return hipGetLastError();
 }
 

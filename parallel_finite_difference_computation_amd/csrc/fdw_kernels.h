@@ -118,8 +118,12 @@ struct BorderArgs {
     float* vel2;                      // its square [nxe][pitch]
     int nx, nz, nxb, nzb, pitch;
 };
-// d_jump: njump matrices M^(31 2^j), row-major 31x31 each; d_out[i] = draw number i counted from window w0
-hipError_t launch_rand_stream(const RandWindow& w0, const unsigned* d_jump, int njump, long long n, int* d_out, hipStream_t s);
+struct RandBase {                     // y[K-31] .. y[K+29]: the window at the position of draw 0 and the next 30 words
+    unsigned y[2 * kRandLag - 1];
+};
+// d_tab: x^(31 l) mod P for l < 64 as [31][64] (coefficient-major), then x^(31 64 h) mod P for block h as [blocks][31];
+// P = x^31 - x^28 - 1 is the characteristic polynomial of the generator.  d_out[i] = draw number i counted from the base.
+hipError_t launch_rand_stream(const RandBase& base, const unsigned* d_tab, long long n, int* d_out, hipStream_t s);
 hipError_t launch_extendvel(const BorderArgs& a, hipStream_t s);
 // d_in [nshots][nx][nt] -> d_out [nshots][nt][nx]
 hipError_t launch_gather_transpose(const float* d_in, float* d_out, int nx, int nt, int nshots, hipStream_t s);
