@@ -11,8 +11,12 @@ N > 1 : launched by torch.distributed.run, one rank per GPU; the SAME grid is sp
         scaling, as BASELINE.json's "RTM domain decomposition, 8192^2 grid, 2->4->8" config asks.
 
 Metric: Gpoints/s = nxe*nze*K / wall (barrier + synchronize on both sides, max over ranks).
-roofline: the step kernel is HBM bound; algorithmic traffic is 16 B/point/step (read p, pp, v2; write
-pp).  `achieved` is measured live with HIP events on the launch stream.
+Timing: the K-step window (barrier + synchronize on both sides) is repeated until 0.3 s have been measured; the MEDIAN window is
+reported, so --steps 20 and --steps 1000 give the same Gpoints/s.
+roofline: bound = HBM.  `achieved` = HBM-side bytes one launch moves / its duration (HIP events on the launch stream): the bytes are the
+rocprofv3 --pmc figure of profiles/traffic.json when that profile was taken on exactly this kernel build (source hash), otherwise the
+minimum one launch must move (12 B in + 8 B out per point for a multi-step pass).  SURVEY.md 8(d)'s 16 B/point/step model -- which a
+temporally blocked kernel beats by construction -- is reported beside it as `algorithmic_16B_model`, never as the fraction.
 cpu_baseline: the oracle's fused C loop (same arithmetic), 1 thread, bounded sample, rank 0, N = 1.
 """
 import argparse
@@ -30,9 +34,65 @@ sys.path.insert(0, ROOT)
 import parallel_finite_difference_computation_amd as F  # noqa: E402
 from parallel_finite_difference_computation_amd.decomp import HipSlabStepper, SlabForward, SlabGeometry  # noqa: E402
 
-ALGO_BYTES_PER_POINT = 16.0   # read p, pp, v2 + write pp
+ALGO_BYTES_PER_POINT = 16.0   # read p, pp, v2 + write pp -- the ONE-step-per-pass byte model
+MIN_BYTES_PER_POINT_PER_LAUNCH = 20.0   # what any launch of the forward kernels must move: read u^n, u^{n-1}, v2 (12 B), write two fields (8 B)
+#                                         (the one-step kernel: 12 + 4 = the 16 B of the model above)
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 ORDER, NB, FAC, DX, DT, FPEAK = 8, 64, 0.75, 10.0, 1.0e-3, 20.0
+MIN_TIMED_SECONDS = 0.3       # the K-step window is repeated until this much time has been measured; the median window is reported
+
+
+def kernel_source_hash():
+    """Identifies the built kernels: profiles/traffic.json (rocprofv3 --pmc passes taken offline) is only quoted for the sources it was taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "parallel_finite_difference_computation_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + [os.path.join(csrc, "fdw_device.h"), os.path.join(csrc, "fdw_kernels.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def offline_counters(workload, n, steps_per_launch):
+    """The entry of profiles/traffic.json for this workload / size / kernel build, or None (a stale profile is never quoted)."""
+    try:
+        entries = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        return None
+    if isinstance(entries, dict):
+        entries = [entries]
+    want = kernel_source_hash()
+    for e in entries:
+        if e.get("workload", "forward") == workload and e.get("size") == n and e.get("steps_per_launch", 1) == steps_per_launch and e.get("source_hash") == want:
+            return e
+    return None
+
+
+def timed_windows(window, sync_all, world, dev, max_windows=400):
+    """Times `window()` (EXACTLY K steps, enqueue only) bracketed by barrier + synchronize on both sides, max over ranks; repeats the window
+    until MIN_TIMED_SECONDS have been measured and returns (median wall seconds, median device ms between HIP events, windows).  A 20-step
+    window at 8192^2 lasts 2.6 ms -- shorter than the clock ramp and than anything that samples the GPU; its median over ~100 windows equals
+    what a 1000-step window gives."""
+    import torch.distributed as dist
+    walls, devs = [], []
+    total = 0.0
+    while True:
+        sync_all()
+        t0 = time.perf_counter()
+        dev_ms = window()
+        sync_all()
+        wall = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([wall], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())            # every rank sees the same number, so every rank stops after the same window
+        walls.append(wall)
+        devs.append(dev_ms)
+        total += wall
+        if total >= MIN_TIMED_SECONDS or len(walls) >= max_windows:
+            break
+    return float(np.median(walls)), float(np.median(devs)), len(walls)
 
 
 def synthetic_velocity_rows(n, row0, rows, device):
@@ -87,22 +147,29 @@ def run_model_workload(args):
     stream.synchronize()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record(stream)
-    run(W, K)
-    e1.record(stream)
-    while not e1.query():
-        pass
-    stream.synchronize()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    if K % 2:
+        sys.exit("bench --workload model: use an even --steps (the two caller-owned buffers swap roles every step)")
+
+    def window():
+        e0.record(stream)
+        run(W, K)
+        e1.record(stream)
+        while not e1.query():
+            pass
+        stream.synchronize()
+        return e0.elapsed_time(e1)
+
+    wall, dev_ms, nwin = timed_windows(window, torch.cuda.synchronize, 1, dev)
     spl = ctx.steps_per_pass()                        # 4: wave pipeline (large grids), 1: one-step kernel
     launches = K // spl + K % spl
-    launch_ms = e0.elapsed_time(e1) / launches
+    launch_s = dev_ms * 1e-3 / launches
     newest = bufs[0]
     finite = bool(torch.isfinite(newest).all().item()) and float(newest.abs().max().item()) > 0.0 and float(rec.abs().max().item()) > 0.0
     algo = ALGO_BYTES_PER_POINT * n * n * spl
-    achieved = algo / (launch_ms * 1e-3) / 1e9
+    min_bytes = (ALGO_BYTES_PER_POINT if spl == 1 else MIN_BYTES_PER_POINT_PER_LAUNCH) * n * n
+    prof = offline_counters("model", n, spl)
+    traffic = prof["hbm_bytes_per_launch"] if prof else None
+    achieved = (traffic if traffic else min_bytes) / launch_s / 1e9
     out = {"metric": "Gpoints/s (stencil updates) + achieved HBM GB/s vs peak", "value": round(n * n * K / wall / 1e9, 3), "unit": "Gpoints/s",
            "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": round(wall * 1e3 / K, 6), "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded noise wavefield)",
@@ -110,9 +177,14 @@ def run_model_workload(args):
                                   f"trace recording fused in one launch per step, {n}x{n} fp32 extended grid, nxb=nzb={NB}, {K} steps",
                       "grid": [n, n], "order": ORDER, "parallelism": "single"},
            "result_finite_nonzero": finite,
+           "timing": {"windows": nwin, "window_steps": K, "statistic": "median window"},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": None, "kernel": "fdw::fdw_stepn_kernel<4,4,true,3,2,true> (four time steps per launch)" if spl == 4 else "fdw::fdw_step_kernel<4,true,3,false,false,2,true>",
-                        "launch_us": round(launch_ms * 1e3, 2), "steps_per_launch": spl, "algorithmic_bytes_per_launch": algo}}
+                        "traffic": traffic, "basis": "measured HBM-side bytes per launch" if traffic else "minimum bytes one launch must move",
+                        "kernel": "fdw::fdw_stepn_kernel<4,4,true,3,2,true> (four time steps per launch)" if spl == 4 else "fdw::fdw_step_kernel<4,true,3,false,false,2,true>",
+                        "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": spl, "min_bytes_per_launch": min_bytes,
+                        "algorithmic_16B_model": {"bytes_per_launch": algo, "achieved": round(algo / launch_s / 1e9, 1),
+                                                  "ratio_to_peak": round(algo / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                                                  "note": "SURVEY.md 8(d)'s one-pass-per-step byte model; can exceed 1 for a temporally blocked launch -- not a roofline fraction"}}}
     if not args.no_cpu_baseline:
         from oracle import oracle as O
         m = min(n, 2048)                       # bounded sample: the oracle's mod loop (with its own allocation and tables) on an m x m grid
@@ -127,6 +199,67 @@ def run_model_workload(args):
     print(json.dumps(out), flush=True)
     if not finite:
         sys.exit("bench: result is not finite / all zero")
+
+
+def run_stencil_workload(args):
+    """`--workload stencil`: the whole device work of `stencil_code` (BASELINE.json config 1's program on a synthetic grid): ONE 8th-order
+    Laplacian of a field (kernel_lap, fd-source-code.cu:110-135, launched once at S:325), device resident.  A "step" is one Laplacian of the grid;
+    algorithmic traffic 8 B/point (read p, write lap)."""
+    n, K, W = args.size, args.steps, args.warmup
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ctx = F.FDWave(ORDER, n, n, NB, NB, 0, 1.0, DX, DX, DT, compat=False, coef_cxx=True)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED0004)
+    p = torch.zeros((n, ctx.pitch), device=dev)
+    p[:, :n] = torch.randn((n, n), device=dev, generator=g)
+    lap = torch.zeros((n, ctx.pitch), device=dev)
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(W):
+        ctx.dev_laplacian(p.data_ptr(), lap.data_ptr(), stream=stream.cuda_stream)
+    stream.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def window():
+        e0.record(stream)
+        for _ in range(K):
+            ctx.dev_laplacian(p.data_ptr(), lap.data_ptr(), stream=stream.cuda_stream)
+        e1.record(stream)
+        while not e1.query():
+            pass
+        stream.synchronize()
+        return e0.elapsed_time(e1)
+
+    wall, dev_ms, nwin = timed_windows(window, torch.cuda.synchronize, 1, dev)
+    launch_s = dev_ms * 1e-3 / K
+    algo = 8.0 * n * n
+    prof = offline_counters("stencil", n, 1)
+    traffic = prof["hbm_bytes_per_launch"] if prof else None
+    achieved = (traffic if traffic else algo) / launch_s / 1e9
+    finite = bool(torch.isfinite(lap).all().item()) and float(lap.abs().max().item()) > 0.0
+    out = {"metric": "Gpoints/s (stencil updates) + achieved HBM GB/s vs peak", "value": round(n * n * K / wall / 1e9, 3), "unit": "Gpoints/s",
+           "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": round(wall * 1e3 / K, 6), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded noise field)",
+           "config": {"workload": f"stencil_code's device work: one 8th-order Laplacian (kernel_lap) of a {n}x{n} fp32 field per step, {K} steps",
+                      "grid": [n, n], "order": ORDER, "parallelism": "single"},
+           "result_finite_nonzero": finite, "timing": {"windows": nwin, "window_steps": K, "statistic": "median window"},
+           "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": traffic, "basis": "measured HBM-side bytes per launch" if traffic else "algorithmic bytes: 8 B/point (read p, write lap)",
+                        "kernel": "fdw::fdw_step_kernel<4,false,0,false,true,2> (Laplacian only)", "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": 1,
+                        "algorithmic_bytes_per_launch": algo}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        m = min(n, 4096)
+        hp = np.random.default_rng(0).standard_normal((m, m), dtype=np.float32)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.0:
+            O.stencil(ORDER, m, m, DX, DX, hp)
+            reps += 1
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(m * m * reps / dt / 1e9, 4), "unit": "Gpoints/s", "cores": 1, "kind": "port",
+                               "sample": f"{reps} Laplacians of a {m}x{m} field, oracle/fdw_oracle.c orc_stencil (gcc -O2 -ffp-contract=off), single thread, {dt:.1f} s"}
+    print(json.dumps(out), flush=True)
 
 
 def run_rtm_workload(args):
@@ -171,6 +304,19 @@ def run_rtm_workload(args):
                                   "2 launches per time index: forward step, fused backward iteration)",
                         "launch_us": round(wall * 1e6 / (2.0 * nt * K / B), 2), "steps_per_launch": 1, "shots_per_launch": B,
                         "algorithmic_bytes_per_launch": 16.0 * nxe * nze * B}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        nts = 250                                      # bounded sample: forward + backward + imaging of one shot cut to 250 time steps (~10 s of one core)
+        orc = O.Oracle(ORDER, nxe, nze, nxb, nzb, nts, 0.75, DX, DX, DT, compat=True)
+        hv2 = np.full((nxe, nze), 2500.0 ** 2, np.float32)
+        hs = F.ricker_wavelet(nts, DT, FPEAK)
+        t0 = time.perf_counter()
+        P, PP = orc.forward(hv2, nxb + 20, nzb, hs)
+        orc.back(hv2, P, PP, np.ascontiguousarray(d_obs[:, :nts]), nzb)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(3.0 * nts * nxe * nze / dt / 1e9, 4), "unit": "Gpoints/s", "cores": 1, "kind": "port",
+                               "sample": f"one shot of the same deck size cut to {nts} forward + {nts} backward iterations with imaging, oracle/fdw_oracle.c "
+                                         f"orc_fd_forward + orc_fd_back (one pass per reference kernel, gcc -O2 -ffp-contract=off), single thread, {dt:.1f} s"}
     print(json.dumps(out), flush=True)
 
 
@@ -183,7 +329,7 @@ def main():
     ap.add_argument("--ksteps", type=int, default=0, help="time steps per halo exchange (N > 1); 0 = auto")
     ap.add_argument("--pipe", choices=("auto", "on", "off"), default="auto",
                     help="N > 1: four-steps-per-pass wave-pipeline kernel inside the slabs (auto = where the library would pick it)")
-    ap.add_argument("--workload", choices=("forward", "model", "rtm"), default="forward",
+    ap.add_argument("--workload", choices=("forward", "model", "rtm", "stencil"), default="forward",
                     help="forward: the headline fused forward step of rtm_code (default); model: the forward-modelling producer; "
                          "rtm: whole RTM shots on the reference's new_mod deck size (both N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -198,7 +344,7 @@ def main():
             sys.exit(f"bench --workload {args.workload} runs on one GPU")
         if not torch.cuda.is_available():
             sys.exit("bench: no GPU visible (the product has no CPU path)")
-        return run_model_workload(args) if args.workload == "model" else run_rtm_workload(args)
+        return {"model": run_model_workload, "rtm": run_rtm_workload, "stencil": run_stencil_workload}[args.workload](args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -279,18 +425,18 @@ def main():
         torch.cuda.synchronize()       # the fills above ran on torch's default stream; `stream` does not wait for it by itself
         run(0, W)
         stream.synchronize()
-        sync_all()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record(stream)
-        run(W, K)
-        e1.record(stream)
-        while not e1.query():      # spin: hipStreamSynchronize naps in ms-sized steps
-            pass
-        stream.synchronize()
-        sync_all()
-        wall = time.perf_counter() - t0
-        dev_ms = e0.elapsed_time(e1)
+
+        def window():
+            e0.record(stream)
+            run(W, K)
+            e1.record(stream)
+            while not e1.query():      # spin: hipStreamSynchronize naps in ms-sized steps
+                pass
+            stream.synchronize()
+            return e0.elapsed_time(e1)
+
+        wall, dev_ms, nwin = timed_windows(window, sync_all, world, dev)
         newest = bufs[roles["ipp"]]
     else:
         a = torch.zeros((geom.nxl, pitch), device=dev)
@@ -306,23 +452,20 @@ def main():
         torch.cuda.synchronize()       # fields were filled on torch's default stream; the driver's streams do not wait for it
         fw.run(W)
         fw.synchronize()       # also forces torch's lazy creation of both streams outside the timed region
-        sync_all()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record(fw.compute)
-        fw.run(K)
-        e1.record(fw.compute)
-        while not e1.query():
-            pass
-        fw.synchronize()
-        sync_all()
-        wall = time.perf_counter() - t0
-        dev_ms = e0.elapsed_time(e1)
+
+        def window():
+            fw.it = W              # the source samples of the timed window every time (srce holds W + K of them)
+            e0.record(fw.compute)
+            fw.run(K)
+            e1.record(fw.compute)
+            while not e1.query():
+                pass
+            fw.synchronize()
+            return e0.elapsed_time(e1)
+
+        wall, dev_ms, nwin = timed_windows(window, sync_all, world, dev)
         newest = fw.owned(fw.d_pp)
-    if world > 1:
-        t = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
     finite = bool(torch.isfinite(newest).all().item()) and float(newest.abs().max().item()) > 0.0
     if world > 1:
         f = torch.tensor([1.0 if finite else 0.0], device=dev)
@@ -371,34 +514,47 @@ def main():
                        "grid": [n, n], "order": ORDER, "parallelism": f"slab{world}" if world > 1 else "single"},
             "result_finite_nonzero": finite,
         }
+        out["timing"] = {"windows": nwin, "window_steps": K, "statistic": "median window (each bracketed by barrier + synchronize, max over ranks)",
+                         "measured_seconds_min": MIN_TIMED_SECONDS}
+        model_note = ("SURVEY.md 8(d)'s one-pass-per-step byte model (16 B/point/step x the steps one launch advances); a temporally blocked launch "
+                      "moves a fraction of it, so this ratio can exceed 1 -- it is a throughput figure in bytes, NOT a roofline fraction")
         if world == 1:
             steps_per_launch = ctx.steps_per_pass()          # 4: wave pipeline, 2: two-step kernel, 1: one-step kernel
             rem = K % steps_per_launch
             launches = K // steps_per_launch + (rem // 2 + rem % 2 if ctx.two_step_active() else rem)
             kname = {4: "fdw::fdw_stepn_kernel<4,4,true,1,2,false> (four time steps per launch: one wave per time level, rows handed through LDS)",
                      2: "fdw::fdw_step2_kernel<4,true,1,false,2> (two time steps per launch)", 1: "fdw::fdw_step_kernel<4,true,1,false,false,2>"}[steps_per_launch]
-            launch_ms = dev_ms / launches
+            launch_s = dev_ms * 1e-3 / launches
             algo = ALGO_BYTES_PER_POINT * pts_per_launch * steps_per_launch      # 16 B/point/step x steps in one launch
-            achieved = algo / (launch_ms * 1e-3) / 1e9
+            min_bytes = (ALGO_BYTES_PER_POINT if steps_per_launch == 1 else MIN_BYTES_PER_POINT_PER_LAUNCH) * pts_per_launch
+            prof = offline_counters("forward", n, steps_per_launch)
+            traffic = prof["hbm_bytes_per_launch"] if prof else None
+            basis_bytes = traffic if traffic else min_bytes
+            achieved = basis_bytes / launch_s / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                               "kernel": kname,
-                               "launch_us": round(launch_ms * 1e3, 2), "steps_per_launch": steps_per_launch,
-                               "algorithmic_bytes_per_launch": algo}
-            traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(traffic_file):   # HBM bytes per launch from the committed rocprofv3 --pmc passes
-                try:
-                    t = json.load(open(traffic_file))
-                    if t.get("size") == n and t.get("steps_per_launch", 1) == steps_per_launch:
-                        out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-                except Exception:
-                    pass
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "basis": ("HBM-side bytes per launch measured with rocprofv3 --pmc (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) / launch time of this run"
+                                         if traffic else "minimum bytes one launch must move (read u^n, u^(n-1), v2; write the fields it produces) / launch time of this run"),
+                               "traffic_source": (f"offline profile {prof.get('source')} taken on kernel sources {prof.get('source_hash')} (= this build)" if prof else
+                                                  "none: profiles/traffic.json holds no entry for this size / kernel build (a stale profile is never quoted)"),
+                               "kernel": kname, "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": steps_per_launch,
+                               "min_bytes_per_launch": min_bytes, "min_bytes_frac": round(min_bytes / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                               "algorithmic_16B_model": {"bytes_per_launch": algo, "achieved": round(algo / launch_s / 1e9, 1),
+                                                         "ratio_to_peak": round(algo / launch_s / 1e9 / HBM_PEAK_GBS, 4), "note": model_note}}
+            if prof and prof.get("valu_busy") is not None:
+                out["roofline"]["issue"] = {"bound": "valu-issue", "valu_busy": prof["valu_busy"], "salu_per_valu": prof.get("salu_per_valu"),
+                                            "source": prof.get("sq_source"),
+                                            "note": "SQ counters: the kernel saturates the vector issue slots well below the HBM line; see DESIGN.md section 4"}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(n)
         else:
-            out["roofline"] = {"bound": "hbm", "achieved": round(ALGO_BYTES_PER_POINT * n * n * K / wall / 1e9, 1),
-                               "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                               "frac": round(ALGO_BYTES_PER_POINT * n * n * K / wall / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None}
+            passes_bytes = (MIN_BYTES_PER_POINT_PER_LAUNCH / 4.0 if use_pipe else ALGO_BYTES_PER_POINT) * n * n * K      # whole job, ghost rows not counted
+            algo = ALGO_BYTES_PER_POINT * n * n * K
+            out["roofline"] = {"bound": "hbm", "achieved": round(passes_bytes / wall / 1e9, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                               "frac": round(passes_bytes / wall / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None,
+                               "basis": "minimum bytes the job's launches must move (owned rows only) / wall time of the median window, against N x the HBM peak",
+                               "algorithmic_16B_model": {"bytes": algo, "achieved": round(algo / wall / 1e9, 1),
+                                                         "ratio_to_peak": round(algo / wall / 1e9 / (HBM_PEAK_GBS * world), 4), "note": model_note}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -140,6 +140,15 @@ int fdw_shot(fdw_ctx *ctx, const float *v2, int sx, int sz, int gz, const float 
  * fdw_dev_steps_shrink  like fdw_dev_steps for one slab of a decomposed grid between two halo exchanges:
  *                 step j = j0.. of the cycle updates rows [h*j, nxl - h*j) on the sides that have a
  *                 neighbour (shrink_lo / shrink_hi), see decomp.py.
+ * fdw_dev_back_iter  ONE iteration of fd_back's loop (R:302-339) on local rows [r0, r1) of a slab (or of the whole grid): with
+ *                 step_source = 1 the source field is reconstructed one step back in time first, F_k = leap-frog(d_f1 = F_{k-1},
+ *                 d_f0 = F_{k-2}) written over d_f0 (R:317-318: no taper, no source); with step_source = 0 (iterations 0 and 1, whose
+ *                 source fields are the two snapshots, R:304-314) d_f1 is used as it stands and d_f0 is ignored.  Then the receiver
+ *                 step (taper + Laplacian + leap-frog, d_pr read, d_ppr overwritten, R:325-327), the injection of d_samples[0..nx)
+ *                 = d_obs[.][nt-1-it] on column gz of the interior rows (R:328) and img += F_k * new receiver field (R:329), where
+ *                 d_img is [nxl][pitch] on the extended grid.  The caller swaps (d_f1, d_f0) when step_source and (d_pr, d_ppr) always.
+ *                 Rows of different calls of one iteration must be disjoint; pp_twice as for fdw_dev_step.  One launch where the fused
+ *                 backward kernel exists (order <= 8), two otherwise.
  * fdw_dev_steps   nsteps FWD steps with internal role swapping; *d_srce is srce[] on the device
  *                 (may be NULL = no source).  After an odd number of steps the newest field is in
  *                 the buffer passed as d_pp, after an even number in d_p (as in the reference loop).
@@ -149,6 +158,8 @@ size_t fdw_field_bytes(const fdw_ctx *ctx);  /* nxl * pitch * 4 */
 int fdw_dev_step(fdw_ctx *ctx, int mode, const float *d_p, float *d_pp, const float *d_v2, int r0, int r1,
                  int pp_twice, const float *d_inj, int inj_x, int inj_z, const float *d_psrc, float *d_img,
                  void *stream);
+int fdw_dev_back_iter(fdw_ctx *ctx, int step_source, const float *d_f1, float *d_f0, const float *d_pr, float *d_ppr, const float *d_v2,
+                      int r0, int r1, int pp_twice, const float *d_samples, int gz, float *d_img, void *stream);
 int fdw_dev_steps(fdw_ctx *ctx, float *d_p, float *d_pp, const float *d_v2, const float *d_srce, int sx, int sz,
                   int it0, int nsteps, int first_pp_twice, void *stream);
 int fdw_dev_steps_shrink(fdw_ctx *ctx, float *d_p, float *d_pp, const float *d_v2, const float *d_srce, int sx, int sz,

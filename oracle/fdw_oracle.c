@@ -206,15 +206,19 @@ void orc_extents(int nxe, int nze, int nzb, int compat, int *xlim, int *zlim, in
 void orc_kernel_lap(int order, int nx, int nz, int gx, int gz, const float *p, float *lap,
                     const float *coefsx, const float *coefsz)
 {
+    /* thread (ti, tj) works on i = h + ti, j = h + tj and returns unless i < nx - h, j < nz - h (R:56-64) */
     int half_order = order / 2, ti, tj, io;
-    for (ti = 0; ti < gx; ti++) {
+    int nti = gx < nx - 2 * half_order ? gx : nx - 2 * half_order;
+    int ntj = gz < nz - 2 * half_order ? gz : nz - 2 * half_order;
+#ifdef _OPENMP
+#pragma omp parallel for private(tj, io) schedule(static)   /* rows are independent; per-point arithmetic unchanged */
+#endif
+    for (ti = 0; ti < nti; ti++) {
         int i = half_order + ti;
-        if (!(i < nx - half_order)) break;
-        for (tj = 0; tj < gz; tj++) {
+        for (tj = 0; tj < ntj; tj++) {
             int j = half_order + tj;
             size_t mult = (size_t)i * nz;
             float acmx = 0, acmz = 0;
-            if (!(j < nz - half_order)) break;
             for (io = 0; io <= order; io++) {
                 int aux = io - half_order;
                 acmz += p[mult + j + aux] * coefsz[io];
@@ -229,8 +233,11 @@ void orc_kernel_lap(int order, int nx, int nz, int gx, int gz, const float *p, f
 void orc_kernel_time(int nx, int nz, int gx, int gz, const float *p, float *pp, const float *v2,
                      const float *lap, float dt2)
 {
-    int i, j;
-    for (i = 0; i < gx && i < nx; i++)
+    int i, j, ni = gx < nx ? gx : nx;
+#ifdef _OPENMP
+#pragma omp parallel for private(j) schedule(static)
+#endif
+    for (i = 0; i < ni; i++)
         for (j = 0; j < gz && j < nz; j++) {
             size_t k = (size_t)i * nz + j;
             pp[k] = 2. * p[k] - pp[k] + v2[k] * dt2 * lap[k];
@@ -277,8 +284,11 @@ void orc_kernel_sism(int nx, int nz, int nxb, int nt, int it, int gz_, int gx, c
 void orc_kernel_img(int nx, int nz, int nxb, int nzb, int gx, int gz, float *imloc, const float *p,
                     const float *ppr)
 {
-    int size_x = nx - 2 * nxb, size_z = nz - 2 * nzb, i, j;
-    for (i = 0; i < gx && i < size_x; i++)
+    int size_x = nx - 2 * nxb, size_z = nz - 2 * nzb, i, j, ni = gx < size_x ? gx : size_x;
+#ifdef _OPENMP
+#pragma omp parallel for private(j) schedule(static)
+#endif
+    for (i = 0; i < ni; i++)
         for (j = 0; j < gz && j < size_z; j++) {
             size_t k = (size_t)(i + nxb) * nz + (j + nzb);
             imloc[(size_t)i * size_z + j] += p[k] * ppr[k];
@@ -435,6 +445,69 @@ void orc_slab_step(const orc_state *s, int x_off, int nxl, float *p, float *pp, 
     }
     l = sx_global - x_off;
     if (sx_global >= 0 && l >= r0 && l < r1) pp[(size_t)l * nze + sz] += srce_it;
+    free(lap);
+}
+
+/* One iteration of fd_back's loop (R:302-339) on rows [r0,r1) of an x-slab, the per-slab restatement behind the CPU (gloo) tests of
+ * decomp.SlabBack -- the reference has no decomposition.  Local arrays hold global rows [x_off, x_off+nxl).
+ *   step_source != 0: F_k = leap-frog(f1 = F_{k-1}, f0 = F_{k-2}) written over f0 (kernel_lap + kernel_time, R:317-318)
+ *   step_source == 0: the source field is f1 as it stands (iterations 0 and 1: the snapshots, R:304-314)
+ *   then kernel_tapper on (pr, ppr) for local rows [t0,t1) (R:325; a caller that splits one iteration into several row ranges damps
+ *   every row it will read exactly once), kernel_lap + kernel_time on the receiver pair (R:326-327), kernel_sism with samples[i] =
+ *   d_obs[i][nt-1-it] (R:328) and kernel_img (R:329) into img[nxl][nze] on the extended grid.  With x_off = 0, nxl = nxe, full ranges
+ *   it is the loop body of orc_fd_back. */
+void orc_slab_back_iter(const orc_state *s, int x_off, int nxl, int step_source, float *f1, float *f0, float *pr, float *ppr,
+                        const float *v2, int r0, int r1, int t0, int t1, const float *samples, int gz_, float *img)
+{
+    const int h = s->order / 2, nze = s->nze, nxe = s->nxe, nx = nxe - 2 * s->nxb, nz = nze - 2 * s->nzb;
+    int l, j, io, pass;
+    float *lap = (float *)calloc((size_t)nxl * nze, sizeof(float));
+    const float *F = step_source ? f0 : f1;
+    for (l = t0; l < t1; l++) {
+        int g = x_off + l, gm = nxe - 1 - g;
+        for (j = 0; j < s->ztap && j < s->nzb; j++) {
+            size_t k = (size_t)l * nze + j;
+            if (g < s->xlim) { pr[k] *= s->taper_z[j]; ppr[k] *= s->taper_z[j]; }
+        }
+        for (j = 0; j < s->ztap && j < s->nzb; j++) {
+            size_t k = (size_t)l * nze + j;
+            if (g < s->nxb && g < s->xlim) { pr[k] *= s->taper_x[g]; ppr[k] *= s->taper_x[g]; }
+            else if (gm < s->nxb && gm < s->xlim) { pr[k] *= s->taper_x[gm]; ppr[k] *= s->taper_x[gm]; }
+        }
+    }
+    for (pass = step_source ? 0 : 1; pass < 2; pass++) {      /* pass 0: the source pair, pass 1: the receiver pair */
+        const float *p = pass == 0 ? f1 : pr;
+        float *pp = pass == 0 ? f0 : ppr;
+        memset(lap, 0, (size_t)nxl * nze * sizeof(float));
+        for (l = r0; l < r1; l++) {
+            int g = x_off + l;
+            if (g < h || g >= nxe - h || g >= h + s->xlim || l < h || l >= nxl - h) continue;
+            for (j = h; j < nze - h && j < h + s->zlim; j++) {
+                float acmx = 0, acmz = 0;
+                for (io = 0; io <= s->order; io++) {
+                    acmz += p[(size_t)l * nze + j + io - h] * s->coefs_z[io];
+                    acmx += p[(size_t)(l + io - h) * nze + j] * s->coefs_x[io];
+                }
+                lap[(size_t)l * nze + j] = acmz + acmx;
+            }
+        }
+        for (l = r0; l < r1; l++) {
+            if (x_off + l >= s->xlim) continue;
+            for (j = 0; j < s->zlim; j++) {
+                size_t k = (size_t)l * nze + j;
+                pp[k] = 2. * p[k] - pp[k] + v2[k] * s->dt2 * lap[k];
+            }
+        }
+    }
+    for (l = r0; l < r1; l++) {
+        int i = x_off + l - s->nxb;                            /* interior row index of kernel_sism / kernel_img */
+        if (i < 0 || i >= nx || i >= s->xlim) continue;
+        ppr[(size_t)l * nze + gz_] += samples[i];
+        for (j = 0; j < s->zlim && j < nz; j++) {
+            size_t k = (size_t)l * nze + (j + s->nzb);
+            img[k] += F[k] * ppr[k];
+        }
+    }
     free(lap);
 }
 

@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_OMP = None
 f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 
 
@@ -18,41 +19,68 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE], stdout=subprocess.DEVNULL)
 
 
-def lib():
-    global _LIB
+def host_threads():
+    """Threads this process may really use: the affinity mask, the cgroup CPU quota if there is one, and at most FDW_CPU_THREADS
+    (default 16 = the CPU share of a one-GPU box; the machine itself may show hundreds of hardware threads)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("FDW_CPU_THREADS", "16"))))
+
+
+def lib(omp=False):
+    """liborc.so; omp=True: the OpenMP build of the same file (rows of the lap / time / img passes shared out over the host threads,
+    per-point arithmetic unchanged -- for the full-size parity tests, where one thread would take minutes)."""
+    global _LIB, _OMP
+    if omp:
+        if _OMP is None:
+            os.environ.setdefault("OMP_NUM_THREADS", str(host_threads()))      # read by libgomp when the library is loaded
+            so = os.path.join(_HERE, "liborc_omp.so")
+            if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "fdw_oracle.c")):
+                build()
+            _OMP = _declare(C.CDLL(so))
+        return _OMP
     if _LIB is None:
         so = os.path.join(_HERE, "liborc.so")
         src = os.path.join(_HERE, "fdw_oracle.c")
         if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
             build()
-        L = C.CDLL(so)
-        L.orc_calc_coefs.argtypes = [C.c_int, C.c_int, f32p]
-        L.orc_scaled_coefs.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, f32p, f32p]
-        L.orc_taper_tables.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
-        L.orc_ricker_wavelet.argtypes = [C.c_int, C.c_float, C.c_float, f32p]
-        L.orc_extendvel_linear.argtypes = [C.c_int] * 4 + [f32p]
-        L.orc_srand.argtypes = [C.c_uint]
-        L.orc_extents.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)] * 3
-        L.orc_init.restype = C.c_void_p
-        L.orc_init.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [C.c_int]
-        L.orc_free.argtypes = [C.c_void_p]
-        L.orc_fd_forward.argtypes = [C.c_void_p, f32p, f32p, f32p, C.c_int, C.c_int, f32p, C.c_int]
-        L.orc_fd_back.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, f32p, C.c_int]
-        L.orc_slab_step.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, f32p, f32p] + [C.c_int] * 6 + [C.c_float]
-        L.orc_stencil.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f32p, f32p]
-        L.orc_fused_steps.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, C.c_float, C.c_int]
-        L.orc_mod_taper_tables.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
-        L.orc_mod_extendvel.argtypes = [C.c_int] * 4 + [f32p]
-        L.orc_mod_ricker_wavelet.argtypes = [C.c_int, C.c_float, C.c_float, f32p]
-        L.orc_mod_taper_apply.argtypes = [f32p] + [C.c_int] * 4 + [f32p, f32p]
-        L.orc_mod_fd_step.argtypes = [C.c_int, f32p, C.c_float, C.c_float, C.c_float, f32p, f32p, f32p, f32p, C.c_int, C.c_int]
-        L.orc_mod_ptsrc.argtypes = [C.c_int] * 4 + [C.c_float, f32p]
-        L.orc_mod_shot.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p]
-        L.orc_mod_taper_apply2.argtypes = [f32p] + [C.c_int] * 4 + [f32p, f32p]
-        L.orc_image_laplacian.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p]
-        L.orc_rtm_stored_shot.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_size_t, C.c_int, f32p]
-        _LIB = L
+        _LIB = _declare(C.CDLL(so))
     return _LIB
+
+
+def _declare(L):
+    L.orc_calc_coefs.argtypes = [C.c_int, C.c_int, f32p]
+    L.orc_scaled_coefs.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, f32p, f32p]
+    L.orc_taper_tables.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
+    L.orc_ricker_wavelet.argtypes = [C.c_int, C.c_float, C.c_float, f32p]
+    L.orc_extendvel_linear.argtypes = [C.c_int] * 4 + [f32p]
+    L.orc_srand.argtypes = [C.c_uint]
+    L.orc_extents.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)] * 3
+    L.orc_init.restype = C.c_void_p
+    L.orc_init.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [C.c_int]
+    L.orc_free.argtypes = [C.c_void_p]
+    L.orc_fd_forward.argtypes = [C.c_void_p, f32p, f32p, f32p, C.c_int, C.c_int, f32p, C.c_int]
+    L.orc_fd_back.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, f32p, C.c_int]
+    L.orc_slab_step.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, f32p, f32p] + [C.c_int] * 6 + [C.c_float]
+    L.orc_slab_back_iter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p] + [C.c_int] * 4 + [f32p, C.c_int, f32p]
+    L.orc_stencil.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f32p, f32p]
+    L.orc_fused_steps.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, C.c_float, C.c_int]
+    L.orc_mod_taper_tables.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
+    L.orc_mod_extendvel.argtypes = [C.c_int] * 4 + [f32p]
+    L.orc_mod_ricker_wavelet.argtypes = [C.c_int, C.c_float, C.c_float, f32p]
+    L.orc_mod_taper_apply.argtypes = [f32p] + [C.c_int] * 4 + [f32p, f32p]
+    L.orc_mod_fd_step.argtypes = [C.c_int, f32p, C.c_float, C.c_float, C.c_float, f32p, f32p, f32p, f32p, C.c_int, C.c_int]
+    L.orc_mod_ptsrc.argtypes = [C.c_int] * 4 + [C.c_float, f32p]
+    L.orc_mod_shot.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p]
+    L.orc_mod_taper_apply2.argtypes = [f32p] + [C.c_int] * 4 + [f32p, f32p]
+    L.orc_image_laplacian.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p]
+    L.orc_rtm_stored_shot.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_size_t, C.c_int, f32p]
+    return L
 
 
 def ref_lib():
@@ -118,16 +146,17 @@ def stencil(order, nxe, nze, dx, dz, field):
 class Oracle:
     """State of one reference fd_init (R:200-224) on the CPU."""
 
-    def __init__(self, order, nxe, nze, nxb, nzb, nt, fac, dx, dz, dt, compat=True):
+    def __init__(self, order, nxe, nze, nxb, nzb, nt, fac, dx, dz, dt, compat=True, omp=False):
         self.shape = (nxe, nze)
         self.nx, self.nz, self.nt = nxe - 2 * nxb, nze - 2 * nzb, nt
-        self._h = lib().orc_init(order, nxe, nze, nxb, nzb, nt, fac, dx, dz, dt, int(compat))
+        self._lib = lib(omp)
+        self._h = self._lib.orc_init(order, nxe, nze, nxb, nzb, nt, fac, dx, dz, dt, int(compat))
         if not self._h:
             raise ValueError("orc_init rejected the parameters")
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_free(self._h)
+            self._lib.orc_free(self._h)
             self._h = None
 
     def forward(self, v2, sx, sz, srce, p=None, pp=None, nsteps=None):
@@ -135,7 +164,7 @@ class Oracle:
         p = np.zeros(self.shape, np.float32) if p is None else np.array(p, np.float32, order="C")
         pp = np.zeros(self.shape, np.float32) if pp is None else np.array(pp, np.float32, order="C")
         nsteps = len(srce) if nsteps is None else nsteps
-        lib().orc_fd_forward(self._h, p, pp, np.ascontiguousarray(v2, np.float32), sx, sz,
+        self._lib.orc_fd_forward(self._h, p, pp, np.ascontiguousarray(v2, np.float32), sx, sz,
                              np.ascontiguousarray(srce, np.float32), nsteps)
         return p, pp
 
@@ -145,7 +174,13 @@ class Oracle:
         nxl = p.shape[0]
         assert p.shape == pp.shape == v2.shape and p.dtype == np.float32 and p.flags.c_contiguous
         t0, t1 = (0, nxl) if taper_rows is None else taper_rows
-        lib().orc_slab_step(self._h, x_off, nxl, p, pp, v2, r0, r1, t0, t1, sx, sz, srce_it)
+        self._lib.orc_slab_step(self._h, x_off, nxl, p, pp, v2, r0, r1, t0, t1, sx, sz, srce_it)
+
+    def slab_back_iter(self, x_off, step_source, f1, f0, pr, ppr, v2, r0, r1, samples, gz, img, taper_rows=None):
+        """One iteration of fd_back's loop on rows [r0,r1) of a slab (local arrays, in place).  Tests only."""
+        nxl = pr.shape[0]
+        t0, t1 = (0, nxl) if taper_rows is None else taper_rows
+        self._lib.orc_slab_back_iter(self._h, x_off, nxl, int(step_source), f1, f0, pr, ppr, v2, r0, r1, t0, t1, np.ascontiguousarray(samples, np.float32), gz, img)
 
     def back(self, v2, snap0, snap1, d_obs, gz, imloc=None, nsteps=None):
         """R:290-341.  d_obs is [nx][nt]; returns imloc [nx][nz]."""
@@ -153,7 +188,7 @@ class Oracle:
         nsteps = self.nt if nsteps is None else nsteps
         d_obs = np.ascontiguousarray(d_obs, np.float32)
         assert d_obs.shape == (self.nx, self.nt)
-        lib().orc_fd_back(self._h, np.ascontiguousarray(v2, np.float32), np.ascontiguousarray(snap0, np.float32),
+        self._lib.orc_fd_back(self._h, np.ascontiguousarray(v2, np.float32), np.ascontiguousarray(snap0, np.float32),
                           np.ascontiguousarray(snap1, np.float32), d_obs, gz, imloc, nsteps)
         return imloc
 

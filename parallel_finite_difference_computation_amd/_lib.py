@@ -45,6 +45,7 @@ SIGNATURES = [
     ("fdw_pitch", C.c_int, [vp]),
     ("fdw_field_bytes", C.c_size_t, [vp]),
     ("fdw_dev_step", C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),
+    ("fdw_dev_back_iter", C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp]),
     ("fdw_dev_steps", C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     ("fdw_dev_steps_shrink", C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 8 + [vp]),
     ("fdw_dev_step2", C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]),

@@ -261,6 +261,10 @@ class FDWave:
         check(lib().fdw_dev_step(self._h, mode, d_p, d_pp, d_v2, r0, r1, int(pp_twice), d_inj, inj_x, inj_z,
                                  d_psrc, d_img, stream))
 
+    def dev_back_iter(self, step_source, d_f1, d_f0, d_pr, d_ppr, d_v2, r0, r1, pp_twice, d_samples, gz, d_img, stream=None):
+        """One iteration of fd_back's loop (fd-code.cu:302-339) on local rows [r0, r1): see fdwave.h."""
+        check(lib().fdw_dev_back_iter(self._h, int(step_source), d_f1, d_f0, d_pr, d_ppr, d_v2, r0, r1, int(pp_twice), d_samples, gz, d_img, stream))
+
     def dev_steps(self, d_p, d_pp, d_v2, d_srce, sx, sz, it0, nsteps, first_pp_twice=False, stream=None):
         check(lib().fdw_dev_steps(self._h, d_p, d_pp, d_v2, d_srce, sx, sz, it0, nsteps, int(first_pp_twice), stream))
 

@@ -460,6 +460,23 @@ extern "C" int fdw_dev_step(fdw_ctx* c, int mode, const float* d_p, float* d_pp,
     return step_impl(c, mode, d_p, d_pp, d_v2, r0, r1, pp_twice, d_inj, inj_x, inj_z, d_psrc, d_img, pick_stream(c, stream));
 }
 
+// One iteration of fd_back's loop (R:302-339) on rows [r0, r1) of the slab, on caller-owned device arrays.
+extern "C" int fdw_dev_back_iter(fdw_ctx* c, int step_source, const float* d_f1, float* d_f0, const float* d_pr, float* d_ppr, const float* d_v2,
+                                 int r0, int r1, int pp_twice, const float* d_samples, int gz, float* d_img, void* stream)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    if (c->prm.dialect != FDW_DIALECT_RTM) return fail(FDW_ESTATE, "fdw_dev_back_iter belongs to the RTM dialect");
+    if (!d_f1 || !d_pr || !d_ppr || !d_v2 || !d_samples || !d_img || (step_source && !d_f0)) return fail(FDW_EINVAL, "back_iter: NULL buffer");
+    hipStream_t s = pick_stream(c, stream);
+    if (!step_source)      // iterations 0 and 1: the source field is a snapshot as it stands (R:304-314)
+        return step_impl(c, FDW_MODE_RECV, d_pr, d_ppr, d_v2, r0, r1, pp_twice, d_samples, 0, gz, d_f1, d_img, s);
+    if (c->h <= kMaxFastHalfOrder && !c->use_generic && !c->no_fused_back)
+        return step_impl(c, FDW_MODE_BACK, d_pr, d_ppr, d_v2, r0, r1, pp_twice, d_samples, 0, gz, d_f1, d_img, s, nullptr, 0, d_f0);
+    int rc = step_impl(c, FDW_MODE_PLAIN, d_f1, d_f0, d_v2, r0, r1, 0, nullptr, -1, 0, nullptr, nullptr, s);      // F_k overwrites F_{k-2} (R:317-318)
+    if (rc) return rc;
+    return step_impl(c, FDW_MODE_RECV, d_pr, d_ppr, d_v2, r0, r1, pp_twice, d_samples, 0, gz, d_f0, d_img, s);
+}
+
 extern "C" int fdw_dev_laplacian(fdw_ctx* c, const float* d_p, float* d_lap, void* stream)
 {
     if (!c) return fail(FDW_EINVAL, "ctx is NULL");

@@ -18,6 +18,10 @@ decomposed result is bit-identical to the single-slab result.
 
 The stepper is pluggable so that the exchange logic can be exercised on CPU (gloo, world_size 2)
 with the oracle as the compute kernel (tests only); the product path uses `HipSlabStepper`.
+
+`SlabBack` decomposes the backward loop the same way (fd-code.cu:302-339): FOUR fields travel per exchange (the source-field pair
+that is reconstructed backwards in time and the receiver-field pair), receiver injection and the imaging condition are local to the
+rows a slab holds, the image never travels and only its owned rows are meaningful.
 """
 from dataclasses import dataclass
 
@@ -92,41 +96,29 @@ class HipSlabStepper:
                                   sx, sz, it0, nsteps, not first, j0, shrink_lo, shrink_hi, stream=stream)
 
 
-class SlabForward:
-    """fd_forward's loop (fd-code.cu:259-267) on one slab of a decomposed grid."""
+class _SlabLoop:
+    """What the forward and the backward slab drivers share: streams, the halo exchange of `exchange_fields()` (by ROLE, so that the
+    message order is the same on every rank) and the cycle loop.  A subclass provides exchange_fields() and cycle(kk, more_after, stream)."""
 
-    PIPE = 4          # time steps per pass of the wave-pipeline kernel (fdw_dev_step4)
-
-    def __init__(self, geom, stepper, fields, v2, srce=None, sx=-1, sz=0, group=None, overlap=True, pipe_ctx=None):
-        """fields: two [nxl][pitch] tensors whose roles swap every step, or FOUR when `pipe_ctx` (the slab's FDWave
-        context) is given: full cycles then go four steps per pass through the wave-pipeline kernel, out of place over the
-        four rotating buffers (needs ksteps % 4 == 0 and order 8)."""
-        self.g, self.stepper = geom, stepper
-        self.bufs = list(fields)
-        self.a, self.b = self.bufs[0], self.bufs[1]
-        self.pipe_ctx = pipe_ctx if (pipe_ctx is not None and len(self.bufs) == 4 and geom.ksteps % self.PIPE == 0 and geom.h == 4) else None
-        self.v2, self.srce, self.sx, self.sz = v2, srce, sx, sz
-        self.group = group
-        self.cuda = self.a.is_cuda
-        self.overlap = overlap
-        self.it = 0
-        self.d_p, self.d_pp = self.a, self.b       # the reference's (d_p, d_pp) BEFORE its swap: d_pp is the newest field
+    def _init_loop(self, geom, group, overlap, cuda, side_stream):
+        self.g, self.group, self.cuda, self.overlap = geom, group, cuda, overlap
         self._ops = {}
-        self.fresh = False          # ghosts of both fields are up to date
+        self.fresh = False          # ghosts of all travelling fields are up to date
         if geom.world > 1 and (geom.o1 - geom.o0) < 2 * geom.G:
             self.overlap = False    # strips would collide: fall back to exchange-then-compute
         self._send_after = None     # stream whose queued work the next exchange has to wait for (default: compute)
+        self.side = None
         if self.cuda:
             self.compute = torch.cuda.Stream()
             self.comm = torch.cuda.Stream()
-            self.side = torch.cuda.Stream() if self.pipe_ctx is not None else None   # boundary strips of a split pipeline pass
+            self.side = torch.cuda.Stream() if side_stream else None   # boundary strips of a split pass
             torch.cuda.synchronize()    # whatever filled the fields (another stream) must have landed before these streams touch them
 
     # ---- halo exchange ------------------------------------------------------------------------
     def _exchange_ops(self):
-        """P2P descriptors for both time levels of the current pair, built once per buffer (the views alias fixed memory)."""
+        """P2P descriptors for every travelling field, built once per buffer (the views alias fixed memory)."""
         g, out = self.g, []
-        for f in (self.d_p, self.d_pp):          # by ROLE: every rank is in the same state, so the message order matches
+        for f in self.exchange_fields():         # by ROLE: every rank is in the same state, so the message order matches
             key = f.data_ptr()
             if key not in self._ops:
                 ops = []
@@ -145,9 +137,9 @@ class SlabForward:
         return out
 
     def exchange(self, wait_compute=True):
-        """Refresh the ghost rows of both fields.  On GPU the transfer runs on the comm stream: it
-        starts after everything already queued on the compute stream (or after `self._halo_ready`
-        when the caller recorded one) and the compute stream is NOT made to wait here."""
+        """Refresh the ghost rows of the travelling fields.  On GPU the transfer runs on the comm stream: it
+        starts after everything already queued on the compute stream (or on the stream recorded in
+        `self._send_after`) and the compute stream is NOT made to wait here."""
         ops = self._exchange_ops()
         if not ops:
             return
@@ -169,6 +161,61 @@ class SlabForward:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         self.fresh = True
+
+    def run(self, nsteps):
+        """nsteps iterations.  Cycle = exchange, then ksteps iterations on shrinking row ranges.
+        With overlap the exchange that opens the NEXT cycle is started as soon as the boundary
+        strips of the cycle's last iteration exist, and runs beside that iteration's interior rows."""
+        g = self.g
+        stream = self.compute.cuda_stream if self.cuda else None
+        done = 0
+        while done < nsteps:
+            kk = min(g.ksteps, nsteps - done)
+            for tag in self.cycle(kk, done + kk < nsteps, stream):
+                if g.world == 1:
+                    continue
+                if tag == "pre":
+                    if not self.fresh:
+                        self.exchange()
+                    if self.cuda:
+                        self.compute.wait_stream(self.comm)    # ghosts must have landed before they are read
+                    self.fresh = False
+                else:
+                    self.exchange()
+            done += kk
+
+    def synchronize(self):
+        if self.cuda:
+            self.compute.synchronize()
+            self.comm.synchronize()
+            if self.side is not None:
+                self.side.synchronize()
+
+    def owned(self, f):
+        """The owned rows of a local field (drops ghosts)."""
+        return f[self.g.g_lo:self.g.nxl - self.g.g_hi]
+
+
+class SlabForward(_SlabLoop):
+    """fd_forward's loop (fd-code.cu:259-267) on one slab of a decomposed grid."""
+
+    PIPE = 4          # time steps per pass of the wave-pipeline kernel (fdw_dev_step4)
+
+    def __init__(self, geom, stepper, fields, v2, srce=None, sx=-1, sz=0, group=None, overlap=True, pipe_ctx=None):
+        """fields: two [nxl][pitch] tensors whose roles swap every step, or FOUR when `pipe_ctx` (the slab's FDWave
+        context) is given: full cycles then go four steps per pass through the wave-pipeline kernel, out of place over the
+        four rotating buffers (needs ksteps % 4 == 0 and order 8)."""
+        self.stepper = stepper
+        self.bufs = list(fields)
+        self.a, self.b = self.bufs[0], self.bufs[1]
+        self.pipe_ctx = pipe_ctx if (pipe_ctx is not None and len(self.bufs) == 4 and geom.ksteps % self.PIPE == 0 and geom.h == 4) else None
+        self.v2, self.srce, self.sx, self.sz = v2, srce, sx, sz
+        self.it = 0
+        self.d_p, self.d_pp = self.a, self.b       # the reference's (d_p, d_pp) BEFORE its swap: d_pp is the newest field
+        self._init_loop(geom, group, overlap, self.a.is_cuda, self.pipe_ctx is not None)
+
+    def exchange_fields(self):
+        return (self.d_p, self.d_pp)
 
     # ---- time loop ----------------------------------------------------------------------------
     def _step(self, r0, r1, stream):
@@ -249,35 +296,83 @@ class SlabForward:
             self.it += P
 
     def run(self, nsteps):
-        """nsteps forward iterations.  Cycle = exchange, then ksteps steps on shrinking row ranges.
-        With overlap the exchange that opens the NEXT cycle is started as soon as the two boundary
-        strips of the cycle's last step exist, and runs beside that step's interior rows."""
-        g = self.g
-        stream = self.compute.cuda_stream if self.cuda else None
-        done = 0
-        while done < nsteps:
-            kk = min(g.ksteps, nsteps - done)
-            for tag in self.cycle(kk, done + kk < nsteps, stream):
-                if g.world == 1:
-                    continue
-                if tag == "pre":
-                    if not self.fresh:
-                        self.exchange()
-                    if self.cuda:
-                        self.compute.wait_stream(self.comm)    # ghosts must have landed before they are read
-                    self.fresh = False
-                else:
-                    self.exchange()
-            done += kk
+        """nsteps forward iterations; returns the reference's (d_p, d_pp) after the loop."""
+        super().run(nsteps)
         return self.d_p, self.d_pp
 
-    def synchronize(self):
-        if self.cuda:
-            self.compute.synchronize()
-            self.comm.synchronize()
-            if self.side is not None:
-                self.side.synchronize()
 
-    def owned(self, f):
-        """The owned rows of a local field (drops ghosts)."""
-        return f[self.g.g_lo:self.g.nxl - self.g.g_hi]
+class HipSlabBackStepper:
+    """Product stepper of the backward loop: one iteration of fd_back on the given rows through the slab's FDWave context
+    (one launch: source-field step + receiver step + injection + imaging fused)."""
+
+    def __init__(self, fdwave_ctx):
+        self.ctx = fdwave_ctx
+
+    def back_iter(self, step_source, f1, f0, pr, ppr, v2, r0, r1, it, samples, gz, img, stream):
+        nx = self.ctx.nx
+        self.ctx.dev_back_iter(step_source, f1.data_ptr(), f0.data_ptr(), pr.data_ptr(), ppr.data_ptr(), v2.data_ptr(), r0, r1, it > 0,
+                               samples.data_ptr() + 4 * nx * it, gz, img.data_ptr(), stream=stream)
+
+
+class SlabBack(_SlabLoop):
+    """fd_back's loop (fd-code.cu:302-339) on one slab of a decomposed grid.
+
+    State per slab: the source-field pair (F_{k-1}, F_{k-2}) -- before iteration 2 these are the forward pass's two snapshots
+    (fd-code.cu:304-314) -- the receiver-field pair (r^k, r^{k-1}) and the image accumulator on the slab's rows.  An iteration
+    reconstructs F_k (from iteration 2 on: no taper, no source), advances the receiver field with damping, injects the time-reversed
+    trace samples on column gz of the interior rows and adds F_k * r^{k+1} to the image.  Injection and imaging are pointwise in x, so
+    they are local to whichever slab holds the row (ghost rows recompute them redundantly, as they recompute the fields); only the four
+    fields travel.  Between two exchanges the valid rows shrink by h per iteration on the interior sides, exactly as in SlabForward."""
+
+    def __init__(self, geom, stepper, snaps, rcv, v2, samples, gz, img, nt, group=None, overlap=True):
+        """snaps = (P, PP) of the forward pass on this slab's rows (P = u^{nt-1} damped, PP = u^{nt}: fd-code.cu:502-507); rcv = two zero
+        fields; samples = the shot gather transposed to [nt][nx] with row it = d_obs[.][nt-1-it] (what iteration it injects);
+        img = [nxl][pitch] accumulator (only owned rows are meaningful afterwards)."""
+        self.stepper = stepper
+        self.f1, self.f0 = snaps[0], snaps[1]       # F_{k-1} (newer in backward time), F_{k-2}
+        self.rn, self.ro = rcv[0], rcv[1]           # r^k (d_pr), r^{k-1} (d_ppr)
+        self.v2, self.samples, self.gz, self.img, self.nt = v2, samples, gz, img, nt
+        self.it = 0
+        self._xfields = None
+        self._init_loop(geom, group, overlap, self.f1.is_cuda, False)
+
+    def exchange_fields(self):
+        return self._xfields if self._xfields is not None else (self.f1, self.f0, self.rn, self.ro)
+
+    def _roles_after(self):
+        """(F_{k-1}, F_{k-2}, r^k, r^{k-1}) as the NEXT iteration sees them."""
+        f1, f0 = (self.f0, self.f1) if self.it >= 2 else (self.f1, self.f0)      # F_k was written over F_{k-2}
+        return (f1, f0, self.ro, self.rn)                                        # fd-code.cu:331-333
+
+    def _iter(self, r0, r1, stream):
+        if r1 <= r0:
+            return
+        if self.it < 2:        # the source field is a snapshot as it stands: iteration 0 images u^nt, iteration 1 u^{nt-1}
+            F = self.f0 if self.it == 0 else self.f1
+            self.stepper.back_iter(False, F, F, self.rn, self.ro, self.v2, r0, r1, self.it, self.samples, self.gz, self.img, stream)
+        else:
+            self.stepper.back_iter(True, self.f1, self.f0, self.rn, self.ro, self.v2, r0, r1, self.it, self.samples, self.gz, self.img, stream)
+
+    def _advance(self):
+        self.f1, self.f0, self.rn, self.ro = self._roles_after()
+        self.it += 1
+
+    def cycle(self, kk, more_after, stream):
+        g = self.g
+        yield "pre"
+        split_last = self.overlap and g.world > 1 and kk == g.ksteps and more_after
+        for j in range(1, kk + 1):
+            r0, r1 = g.update_range(j)
+            if split_last and j == kk:
+                lo_end = r0 + g.G if g.has_lo else r0
+                hi_beg = r1 - g.G if g.has_hi else r1
+                self._iter(r0, lo_end, stream)
+                self._iter(hi_beg, r1, stream)
+                self._xfields = self._roles_after()  # what the exchange started at "mid" sends and fills: the next cycle's roles
+                yield "mid"
+                self._xfields = None
+                self._iter(lo_end, hi_beg, stream)   # the interior rows of the same iteration, beside the transfer
+                self._advance()
+            else:
+                self._iter(r0, r1, stream)
+                self._advance()

@@ -50,13 +50,14 @@ def rel_max(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def make_deck(nxe, nze, nxb, nzb, nt, seed=0, order=8, fac=0.75, compat=True, fpeak=20.0):
-    """Small seeded synthetic deck: layered velocity with noise, stable dt."""
+def make_deck(nxe, nze, nxb, nzb, nt, seed=0, order=8, fac=0.75, compat=True, fpeak=20.0, dx=10.0, dz=10.0):
+    """Small seeded synthetic deck: layered velocity with noise, stable dt.  dx != dz as in the reference's marmousi deck
+    (cuda_reference_RTM/models/marmousi/input.dat:7-8: dz=8, dx=25) exercises the separate x / z weight pairs of the packed kernels."""
     rng = np.random.default_rng(seed)
     z = np.arange(nze, dtype=np.float32)[None, :]
     vel = (1500.0 + 2000.0 * z / max(nze - 1, 1) + 200.0 * rng.standard_normal((nxe, nze))).astype(np.float32)
-    vel = np.clip(vel, 1200.0, 4200.0).astype(np.float32)
-    return dict(order=order, nxe=nxe, nze=nze, nxb=nxb, nzb=nzb, nt=nt, fac=fac, dx=10.0, dz=10.0, dt=0.001,
+    vel = np.clip(vel, 1200.0, 4200.0 * min(1.0, min(dx, dz) / 10.0)).astype(np.float32)     # keeps v dt / min(dx, dz) where it was
+    return dict(order=order, nxe=nxe, nze=nze, nxb=nxb, nzb=nzb, nt=nt, fac=fac, dx=float(dx), dz=float(dz), dt=0.001,
                 fpeak=fpeak, compat=compat, v2=(vel * vel).astype(np.float32),
                 sx=nxb + (nxe - 2 * nxb) // 3, sz=nzb + 2, gz=nzb + 1)
 

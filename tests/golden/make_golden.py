@@ -10,6 +10,10 @@ oracle/Makefile from cuda_reference_RTM/lib/src/functions.c).  No reference sour
   stencil_lap_415x295.f32     dpct_migrated_stencil_computation/output_teste.bin (8th-order Laplacian of it)
   new_mod_vel_ext_shot5.f32   slice [5] of cuda_reference_RTM/models/new_mod/vel_ext_rnd.6 (415x295)
   new_mod_vel_koslov.f32      cuda_reference_RTM/models/new_mod/vel-koslov.1 (315x195)
+  new_mod_vel_ext_rnd6.npz    all six slices of cuda_reference_RTM/models/new_mod/vel_ext_rnd.6 (key "vel", [6][415][295], zlib-compressed:
+                              2.9 MB -> 0.9 MB): the per-shot extended velocity models of the reference's own six-shot deck
+  marmousi_model_375.npz      cuda_reference_RTM/models/marmousi/model-375.cwp (key "vp", [369][375]): the velocity model of the reference's
+                              dx = 25 / dz = 8 deck (decks/marmousi.dat)
   host_tables.npz             calc_coefs / ricker_wavelet / extendvel_linear outputs of oracle/_ref
   decks/*.dat                 the reference's input.dat decks (parser fixtures)
   dd_3lay_mod_vp_151x151.f32  dpct_gpu_rtm_domain_division/build/3lay_mod/3layer_151x151.bin (velocity model of the CPU-serial sibling)
@@ -40,6 +44,9 @@ def main():
     cp("cuda_reference_RTM/models/new_mod/vel-koslov.1", "new_mod_vel_koslov.f32")
     vel = np.fromfile(os.path.join(REF, "cuda_reference_RTM/models/new_mod/vel_ext_rnd.6"), np.float32).reshape(6, 415, 295)
     vel[5].tofile(os.path.join(HERE, "new_mod_vel_ext_shot5.f32"))
+    np.savez_compressed(os.path.join(HERE, "new_mod_vel_ext_rnd6.npz"), vel=vel)
+    np.savez_compressed(os.path.join(HERE, "marmousi_model_375.npz"),
+                        vp=np.fromfile(os.path.join(REF, "cuda_reference_RTM/models/marmousi/model-375.cwp"), np.float32).reshape(369, 375))
     for name, src in [("stencil.dat", "cuda_reference_stencil_computation/input.dat"),
                       ("new_mod.dat", "cuda_reference_RTM/models/new_mod/input.dat"),
                       ("marmousi.dat", "cuda_reference_RTM/models/marmousi/input.dat"),

@@ -654,10 +654,12 @@ def test_image_laplacian_known_answer_and_oracle():
 
 
 @pytest.mark.parametrize("n", [4096, 8192, 16384])
-def test_full_size_kernels_agree_and_scale_exactly(n):
-    """BASELINE.json's full-size grids, where the oracle is too slow to be the checker: (a) the three forward kernels (one step, two steps,
-    four steps per pass) agree BITWISE after 9 steps from a noise state with the source on -- the one-step kernel is the one pinned to the
-    oracle at small sizes; (b) linearity: doubling the source doubles the wavefield exactly (a power of two commutes with every rounding)."""
+def test_full_size_kernels_vs_oracle_and_scale_exactly(n):
+    """BASELINE.json's full-size grids (configs 2, 4 and one GPU's worth of 5).  (a) 4096^2 and 8192^2: the one-step kernel AND the kernel
+    bench.py runs there (four steps per pass; 9 steps = two passes + one leftover one-step launch) against the ORACLE's fd_forward loop,
+    bit for bit, from a seeded noise state with the source on (the OpenMP build of oracle/fdw_oracle.c: a few seconds); 16384^2 (1 GiB per
+    field, the oracle would need 6 GiB of host arrays per run) stays kernel against kernel.  (b) the three forward kernels agree bitwise.
+    (c) linearity: doubling the source doubles the wavefield exactly (a power of two commutes with every rounding)."""
     import torch
     dev = torch.device("cuda:0")
     nb, nt = 64, 16
@@ -670,9 +672,10 @@ def test_full_size_kernels_agree_and_scale_exactly(n):
         t[:, :n] = 1e-3 * torch.randn((n, n), device=dev, generator=g)
     v2 = torch.zeros((n, pitch), device=dev)
     v2[:, :n] = (1500.0 + 2500.0 * torch.rand((n, n), device=dev, generator=g)) ** 2
-    srce_h = O.ricker_wavelet(nt, 0.001, 30.0) + 0.25
-    srce = torch.from_numpy(srce_h.astype(np.float32)).to(dev)
+    srce_h = (O.ricker_wavelet(nt, 0.001, 30.0) + 0.25).astype(np.float32)
+    srce = torch.from_numpy(srce_h).to(dev)
     srce2 = 2.0 * srce
+    sx, sz = n // 2 + 3, n // 3
 
     def run(mode, s, from_rest, nsteps=9):
         ctx.set_tuning(two_step=mode)
@@ -681,13 +684,26 @@ def test_full_size_kernels_agree_and_scale_exactly(n):
             bufs[0].copy_(init[0])
             bufs[1].copy_(init[1])
         torch.cuda.synchronize()      # the library launches on its own non-blocking stream: torch's fills must have landed
-        ip, ipp = ctx.dev_steps2([b.data_ptr() for b in bufs], v2.data_ptr(), s.data_ptr(), n // 2 + 3, n // 3, 0, nsteps, False, 0, 1)
+        ip, ipp = ctx.dev_steps2([b.data_ptr() for b in bufs], v2.data_ptr(), s.data_ptr(), sx, sz, 0, nsteps, False, 0, 1)
         torch.cuda.synchronize()
         return bufs[ip], bufs[ipp]
 
     ctx.set_tuning(two_step=0)
     assert ctx.steps_per_pass() == 4                     # what bench.py runs at this size
     ref_p, ref_pp = run(-1, srce, False)
+    if n <= 8192:
+        orc = O.Oracle(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False, omp=True)
+        oP, oPP = orc.forward(v2[:, :n].cpu().numpy(), sx, sz, srce_h, init[0][:, :n].cpu().numpy(), init[1][:, :n].cpu().numpy(), nsteps=9)
+        del orc
+        for mode, name in ((-1, "one-step kernel"), (0, "bench kernel (four steps per pass)")):
+            p, pp = (ref_p, ref_pp) if mode == -1 else run(mode, srce, False)
+            ctx.dev_taper_finalize(p.data_ptr())         # the reference downloads the damped d_p (R:285); the lazy scheme owes it one T
+            torch.cuda.synchronize()
+            assert_bit_equal(pp[:, :n].cpu().numpy(), oPP, f"{name} vs oracle at {n}^2: PP")
+            assert_bit_equal(p[:, :n].cpu().numpy(), oP, f"{name} vs oracle at {n}^2: P")
+            assert not bool(pp[:, n:].any()) and not bool(p[:, n:].any())
+        del oP, oPP
+        ref_p, ref_pp = run(-1, srce, False)             # undamped again for the kernel-against-kernel comparison below
     for mode in (1, 4):
         p, pp = run(mode, srce, False)
         assert torch.equal(pp, ref_pp) and torch.equal(p, ref_p), f"kernel mode {mode} differs from the one-step kernel at {n}^2"
@@ -696,6 +712,29 @@ def test_full_size_kernels_agree_and_scale_exactly(n):
     b_p, b_pp = run(4, srce2, True)
     assert torch.equal(b_pp, 2.0 * a_pp) and torch.equal(b_p, 2.0 * a_p), "doubling the source does not double the field exactly"
     assert float(a_pp.abs().max()) > 0
+
+
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_full_size_backward_and_imaging_vs_oracle(n):
+    """fd_back (source-field reconstruction + receiver step + injection + imaging, R:302-339) at BASELINE.json's full grid sizes against the
+    oracle (OpenMP build), bit for bit: the kernels the library picks there by itself and the one-step kernels, 5 iterations (two pairs + one
+    single where iterations go in pairs) from noise snapshots, image accumulated onto a non-zero one."""
+    nb, nt = 64, 5
+    rng = np.random.default_rng(n)
+    snap0 = (1e-3 * rng.standard_normal((n, n), dtype=np.float32))
+    snap1 = (1e-3 * rng.standard_normal((n, n), dtype=np.float32))
+    v2 = ((1500.0 + 2500.0 * rng.random((n, n), dtype=np.float32)) ** 2).astype(np.float32)
+    d_obs = rng.standard_normal((n - 2 * nb, nt), dtype=np.float32)
+    im0 = rng.standard_normal((n - 2 * nb, n - 2 * nb), dtype=np.float32)
+    gz = nb + 3
+    orc = O.Oracle(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False, omp=True)
+    want = orc.back(v2, snap0, snap1, d_obs, gz, imloc=im0)
+    del orc
+    ctx = F.FDWave(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False)
+    for mode in (0, -1):
+        ctx.set_tuning(two_step=mode)
+        assert_bit_equal(ctx.back(v2, snap0, snap1, d_obs, gz, imloc=im0), want, f"image at {n}^2, two_step={mode}")
+    assert np.abs(want - im0).max() > 0
 
 
 def test_large_ragged_compat_grid_kernels_agree():
@@ -736,6 +775,60 @@ def test_large_ragged_compat_grid_kernels_agree():
             p, pp = run(mode, nsteps)
             assert torch.equal(pp, ref_pp) and torch.equal(p, ref_p), f"mode {mode}, {nsteps} steps"
         assert float(ref_pp.abs().max()) > 0 and bool(torch.isfinite(ref_pp).all())
+
+
+def _lockstep_async(fws, nsteps, ksteps):
+    """Drives several slab drivers (decomp.SlabForward / SlabBack) of ONE process in lockstep with really asynchronous streams: the cycle
+    generators are advanced together on the host; a halo transfer is a device-to-device copy enqueued on the RECEIVER's comm stream that
+    waits (by event) for the SENDER's comm stream, which in turn waited for the sender's compute or side stream exactly as
+    _SlabLoop.exchange() does; the sender's comm stream is held until the copy is done, like a send in flight."""
+    import torch
+    world = len(fws)
+
+    def exchange_all():
+        ready = []
+        for fw in fws:                                            # sender side of exchange(): comm waits for compute / side
+            fw.comm.wait_stream(fw._send_after if fw._send_after is not None else fw.compute)
+            fw._send_after = None
+            ev = torch.cuda.Event()
+            ev.record(fw.comm)
+            ready.append(ev)
+        done = []
+        for r, fw in enumerate(fws):
+            g = fw.g
+            with torch.cuda.stream(fw.comm):
+                for nb_r, recv, send in ((r - 1, g.recv_lo(), "send_hi"), (r + 1, g.recv_hi(), "send_lo")):
+                    if 0 <= nb_r < world and ((nb_r < r and g.has_lo) or (nb_r > r and g.has_hi)):
+                        fw.comm.wait_event(ready[nb_r])
+                        s0, s1 = getattr(fws[nb_r].g, send)()
+                        for mine, theirs in zip(fw.exchange_fields(), fws[nb_r].exchange_fields()):      # by role, like the P2P descriptors
+                            mine[recv[0]:recv[1]].copy_(theirs[s0:s1], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(fw.comm)
+                        done.append((nb_r, ev))
+        for nb_r, ev in done:                                     # a send is in flight until its data has been taken
+            fws[nb_r].comm.wait_event(ev)
+        for fw in fws:
+            fw.fresh = True
+
+    done_steps = 0
+    while done_steps < nsteps:
+        kk = min(ksteps, nsteps - done_steps)
+        gens = [fw.cycle(kk, done_steps + kk < nsteps, fw.compute.cuda_stream) for fw in fws]
+        while True:
+            tags = [next(gn, None) for gn in gens]
+            assert len(set(tags)) == 1, tags
+            if tags[0] is None:
+                break
+            if tags[0] == "pre":                                  # _SlabLoop.run()'s handling of the two yield points
+                if not fws[0].fresh:
+                    exchange_all()
+                for fw in fws:
+                    fw.compute.wait_stream(fw.comm)
+                    fw.fresh = False
+            else:
+                exchange_all()
+        done_steps += kk
 
 
 @pytest.mark.parametrize("world,ksteps,pipe", [(3, 8, True), (2, 4, True), (3, 4, False)], ids=["3slabs-pipeline-k8", "2slabs-pipeline-k4", "3slabs-onestep-k4"])
@@ -787,54 +880,65 @@ def test_slabforward_with_asynchronous_streams_on_one_gpu(world, ksteps, pipe):
         fws.append(fw)
     torch.cuda.synchronize()
 
-    def exchange_all():
-        ready = []
-        for fw in fws:                                            # sender side of SlabForward.exchange(): comm waits for compute / side
-            fw.comm.wait_stream(fw._send_after if fw._send_after is not None else fw.compute)
-            fw._send_after = None
-            ev = torch.cuda.Event()
-            ev.record(fw.comm)
-            ready.append(ev)
-        done = []
-        for r, fw in enumerate(fws):
-            g = fw.g
-            with torch.cuda.stream(fw.comm):
-                for nb_r, recv, send in ((r - 1, g.recv_lo(), "send_hi"), (r + 1, g.recv_hi(), "send_lo")):
-                    if 0 <= nb_r < world and ((nb_r < r and g.has_lo) or (nb_r > r and g.has_hi)):
-                        fw.comm.wait_event(ready[nb_r])
-                        s0, s1 = getattr(fws[nb_r].g, send)()
-                        for mine, theirs in ((fw.d_p, fws[nb_r].d_p), (fw.d_pp, fws[nb_r].d_pp)):
-                            mine[recv[0]:recv[1]].copy_(theirs[s0:s1], non_blocking=True)
-                        ev = torch.cuda.Event()
-                        ev.record(fw.comm)
-                        done.append((nb_r, ev))
-        for nb_r, ev in done:                                     # a send is in flight until its data has been taken
-            fws[nb_r].comm.wait_event(ev)
-        for fw in fws:
-            fw.fresh = True
-
-    done_steps = 0
-    while done_steps < nsteps:
-        kk = min(ksteps, nsteps - done_steps)
-        gens = [fw.cycle(kk, done_steps + kk < nsteps, fw.compute.cuda_stream) for fw in fws]
-        while True:
-            tags = [next(gn, None) for gn in gens]
-            assert len(set(tags)) == 1, tags
-            if tags[0] is None:
-                break
-            if tags[0] == "pre":                                  # SlabForward.run()'s handling of the two yield points
-                if not fws[0].fresh:
-                    exchange_all()
-                for fw in fws:
-                    fw.compute.wait_stream(fw.comm)
-                    fw.fresh = False
-            else:
-                exchange_all()
-        done_steps += kk
+    _lockstep_async(fws, nsteps, ksteps)
     torch.cuda.synchronize()
     own = lambda fw, f: fw.owned(f)[:, :nze]
     assert torch.equal(torch.cat([own(fw, fw.d_pp) for fw in fws]), rb[ipp][:, :nze]), "newest field differs from the single-domain run"
     assert torch.equal(torch.cat([own(fw, fw.d_p) for fw in fws]), rb[ip][:, :nze]), "older field differs from the single-domain run"
+
+
+@pytest.mark.parametrize("world,ksteps,shape,compat", [(3, 4, (700, 900), False), (2, 3, (701, 523), True), (4, 2, (640, 300), True)],
+                         ids=["3slabs-k4", "2slabs-k3-ragged-compat", "4slabs-k2"])
+def test_slabback_with_asynchronous_streams_on_one_gpu(world, ksteps, shape, compat):
+    """Row e2: fd_back + imaging under domain decomposition (decomp.SlabBack over the real per-slab HIP contexts, every slab with its own
+    compute / comm streams on this one GPU, halo transfers as event-ordered device copies, nothing synchronised with the host until the
+    end): the image gathered from the slabs' owned rows equals fdw_shot's single-domain image bit for bit -- full cycles with the
+    exchange overlapped with the interior rows of the split iteration, leftover iterations, ragged extents with the reference's truncated
+    launch grids, stale ghosts at the start."""
+    import torch
+    from parallel_finite_difference_computation_amd.decomp import HipSlabBackStepper, SlabBack, SlabGeometry
+    dev = torch.device("cuda:0")
+    nxe, nze = shape
+    nb, nt = 40, 3 * ksteps + 3
+    d = make_deck(nxe, nze, nb, nb, nt, seed=23, compat=compat)
+    nx, nz = nxe - 2 * nb, nze - 2 * nb
+    rng = np.random.default_rng(31)
+    srce = (O.ricker_wavelet(nt, d["dt"], 30.0) + 0.25).astype(np.float32)
+    d_obs = rng.standard_normal((nx, nt)).astype(np.float32)
+    im0 = rng.standard_normal((nx, nz)).astype(np.float32)
+    ref = mk(d)
+    want, P, PP = ref.shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs, imloc=im0, want_fields=True)
+    assert_bit_equal(want, mko(d).back(d["v2"], P, PP, d_obs, d["gz"], imloc=im0), "single-domain image vs oracle")
+    samples_h = np.ascontiguousarray(d_obs[:, ::-1].T)                      # row it = d_obs[.][nt-1-it]
+    bks = []
+    for r in range(world):
+        g = SlabGeometry(r, world, nxe, 4, ksteps)
+        ctx = mk(d, slab=(g.x_off, g.nxl))
+        rows = slice(g.x_off, g.x_off + g.nxl)
+
+        def dev_field(h):
+            t = torch.zeros((g.nxl, ctx.pitch), device=dev)
+            t[:, :nze] = torch.from_numpy(np.ascontiguousarray(h[rows])).to(dev)
+            return t
+        snaps = [dev_field(P), dev_field(PP)]
+        rcv = [torch.zeros((g.nxl, ctx.pitch), device=dev) for _ in range(2)]
+        if g.has_lo:                                                        # ghosts start stale: the first exchange must bring them
+            snaps[0][:g.g_lo, :nze] = 9.0
+            rcv[1][:g.g_lo, :nze] = -9.0
+        if g.has_hi:
+            snaps[1][g.nxl - g.g_hi:, :nze] = 9.0
+            rcv[0][g.nxl - g.g_hi:, :nze] = -9.0
+        imfull = np.zeros((nxe, nze), np.float32)
+        imfull[nb:nb + nx, nb:nb + nz] = im0
+        bk = SlabBack(g, HipSlabBackStepper(ctx), snaps, rcv, dev_field(d["v2"]), torch.from_numpy(samples_h).to(dev), d["gz"], dev_field(imfull), nt)
+        bk._ctx = ctx
+        bks.append(bk)
+    torch.cuda.synchronize()
+    _lockstep_async(bks, nt, ksteps)
+    torch.cuda.synchronize()
+    got = torch.cat([bk.owned(bk.img)[:, :nze] for bk in bks]).cpu().numpy()[nb:nb + nx, nb:nb + nz]
+    assert_bit_equal(got, want, f"image from {world} slabs")
+    assert np.abs(want - im0).max() > 0
 
 
 @pytest.mark.parametrize("order", [8, 4])
@@ -856,6 +960,56 @@ def test_fused_backward_iteration_equals_two_launches(order, monkeypatch):
         want = orc.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n)
         assert_bit_equal(fused.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n), want, f"fused backward, {n} iterations")
         assert_bit_equal(split.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n), want, f"two-launch backward, {n} iterations")
+
+
+@pytest.mark.parametrize("spacing", [(25.0, 8.0), (8.0, 25.0)], ids=["marmousi-dx25-dz8", "dx8-dz25"])
+@pytest.mark.parametrize("case", [(99, 83, 17, 13, 21, True), (150, 1300, 20, 24, 17, True), (260, 530, 24, 40, 16, False)], ids=lambda c: "x".join(map(str, c)))
+def test_unequal_spacings_through_every_rtm_kernel(case, spacing, monkeypatch):
+    """dx != dz (the reference ships such a deck: models/marmousi/input.dat:7-8, dz = 8, dx = 25) through every kernel of the RTM dialect:
+    one-step, two-step and wave-pipeline forward loops, the fused backward iteration, the two-launch backward iteration, the paired
+    backward iterations of the two-step kernels and a batch of shots -- fields and images equal the oracle's bit for bit.  The packed
+    kernels carry the x and z weights as separate SGPR pairs (fdw_device.h CoefPairs); with dx == dz a mix-up would go unnoticed."""
+    nxe, nze, nxb, nzb, nt, compat = case
+    dx, dz = spacing
+    d = make_deck(nxe, nze, nxb, nzb, nt, seed=41, compat=compat, dx=dx, dz=dz)
+    nx, nz = nxe - 2 * nxb, nze - 2 * nzb
+    rng = np.random.default_rng(12)
+    srce = (O.ricker_wavelet(nt, d["dt"], 30.0) + 0.25).astype(np.float32)
+    p0, pp0 = random_fields(d, seed=14, amp=0.1)
+    d_obs = rng.standard_normal((nx, nt)).astype(np.float32)
+    im0 = rng.standard_normal((nx, nz)).astype(np.float32)
+    ctx, orc = mk(d), mko(d)
+    cx, cz, _, _ = ctx.tables()
+    assert cx[0] != cz[0]                                    # the two axes really carry different weights
+    for mode in (-1, 1, 4):
+        ctx.set_tuning(two_step=mode)
+        for p, pp, n in ((p0, pp0, nt), (None, None, nt), (p0, pp0, 5)):
+            P, PP = ctx.forward(d["v2"], d["sx"], d["sz"], srce, p, pp, nsteps=n)
+            oP, oPP = orc.forward(d["v2"], d["sx"], d["sz"], srce, p, pp, nsteps=n)
+            assert_bit_equal(P, oP, f"P mode={mode} n={n}")
+            assert_bit_equal(PP, oPP, f"PP mode={mode} n={n}")
+    oP, oPP = orc.forward(d["v2"], d["sx"], d["sz"], srce)
+    monkeypatch.setenv("FDW_NO_FUSED_BACK", "1")
+    split = mk(d)
+    monkeypatch.delenv("FDW_NO_FUSED_BACK")
+    for n in (nt, 3, 4):
+        want = orc.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n)
+        for name, c, mode in (("fused BACK", ctx, -1), ("two launches", split, -1), ("two-step pairs", ctx, 1), ("auto", ctx, 0)):
+            c.set_tuning(two_step=mode)
+            assert_bit_equal(c.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n), want, f"image, {name}, {n} iterations")
+    for mode in (0, 4):
+        ctx.set_tuning(two_step=mode)
+        img, P, PP = ctx.shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs, imloc=im0, want_fields=True)
+        assert_bit_equal(P, oP, f"shot P mode={mode}")
+        assert_bit_equal(img, orc.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0), f"shot image mode={mode}")
+    ctx.set_tuning(two_step=0)
+    if compat and nxb + nx <= 8 * (nxe // 8):
+        gathers = rng.standard_normal((3, nx, nt)).astype(np.float32)
+        v2_all = np.stack([d["v2"] * np.float32(1.0 + 0.04 * b) for b in range(3)]).astype(np.float32)
+        got = ctx.shot_batch(3, d["sx"], 2, d["sz"], d["gz"], srce, gathers, v2_all=v2_all)
+        for b in range(3):
+            bP, bPP = orc.forward(v2_all[b], d["sx"] + 2 * b, d["sz"], srce)
+            assert_bit_equal(got[b], orc.back(v2_all[b], bP, bPP, gathers[b], d["gz"]), f"batched shot {b}")
 
 
 def test_random_decks_property():
@@ -882,17 +1036,20 @@ def test_random_decks_property():
         nt = draw(st.integers(2, 9))
         mode = draw(st.sampled_from([-1, 1, 4])) if order == 8 else 0
         fac = draw(st.sampled_from([0.3, 0.75, 1.0]))
+        dx, dz = draw(st.sampled_from([(10.0, 10.0), (25.0, 8.0), (8.0, 12.5), (10.0, 10.0)]))      # marmousi's deck: dx = 25, dz = 8
         return dict(order=order, nxe=nxe, nze=nze, nxb=nxb, nzb=nzb, nt=nt, compat=compat, sx=sx, sz=sz, gz=gz, mode=mode, fac=fac,
-                    seed=draw(st.integers(0, 10**6)))
+                    dx=dx, dz=dz, seed=draw(st.integers(0, 10**6)))
 
-    seen = []
+    seen, spacings = [], set()
 
     @settings(max_examples=int(os.environ.get("FDW_PROPERTY_EXAMPLES", "150")), deadline=None, suppress_health_check=list(HealthCheck),
               derandomize="FDW_PROPERTY_RANDOM" not in os.environ, database=None)
     @given(decks())
     def check(c):
         seen.append((c["order"], c["mode"], c["compat"]))
-        d = make_deck(c["nxe"], c["nze"], c["nxb"], c["nzb"], c["nt"], seed=c["seed"], order=c["order"], compat=c["compat"], fac=c["fac"])
+        spacings.add((c["dx"], c["dz"]))
+        d = make_deck(c["nxe"], c["nze"], c["nxb"], c["nzb"], c["nt"], seed=c["seed"], order=c["order"], compat=c["compat"], fac=c["fac"],
+                      dx=c["dx"], dz=c["dz"])
         nx, nz = c["nxe"] - 2 * c["nxb"], c["nze"] - 2 * c["nzb"]
         srce = (O.ricker_wavelet(c["nt"], d["dt"], 30.0) + 0.5).astype(np.float32)
         d_obs = np.random.default_rng(c["seed"]).standard_normal((nx, c["nt"])).astype(np.float32)
@@ -906,7 +1063,9 @@ def test_random_decks_property():
         assert_bit_equal(img, oimg, f"image {c}")
 
     check()
-    assert len(seen) >= 100 and {m for (o, m, _) in seen if o == 8} == {-1, 1, 4} and {o for (o, _, _) in seen} == {2, 4, 6, 8, 10}, len(seen)
+    orders = {o for (o, _, _) in seen}
+    assert len(seen) >= 100 and {m for (o, m, _) in seen if o == 8} == {-1, 1, 4} and {8, 10} <= orders and len(orders) >= 4, (len(seen), orders)
+    assert spacings == {(10.0, 10.0), (25.0, 8.0), (8.0, 12.5)}
 
 
 def test_random_modelling_and_stored_rtm_decks_property():
@@ -1093,14 +1252,15 @@ def test_random_shot_batches_property():
         dmin = -((sx0 - nxb) // (nshots - 1))
         dsx = draw(st.integers(dmin, dmax))
         sz = draw(st.integers(max(nzb, h), max(max(nzb, h), min(nzb + nz - 1, zlim - 1))))
+        dx, dz = draw(st.sampled_from([(10.0, 10.0), (25.0, 8.0), (8.0, 12.5)]))
         return dict(order=order, nxe=nxe, nze=nze, nxb=nxb, nzb=nzb, nt=draw(st.integers(2, 8)), compat=compat, nshots=nshots, sx0=sx0, dsx=dsx, sz=sz,
-                    gz=draw(st.integers(nzb, nzb + nz - 1)), seed=draw(st.integers(0, 10**6)))
+                    gz=draw(st.integers(nzb, nzb + nz - 1)), dx=dx, dz=dz, seed=draw(st.integers(0, 10**6)))
 
     @settings(max_examples=int(os.environ.get("FDW_PROPERTY_EXAMPLES", "60")), deadline=None, suppress_health_check=list(HealthCheck),
               derandomize="FDW_PROPERTY_RANDOM" not in os.environ, database=None)
     @given(decks())
     def check(c):
-        d = make_deck(c["nxe"], c["nze"], c["nxb"], c["nzb"], c["nt"], seed=c["seed"], order=c["order"], compat=c["compat"])
+        d = make_deck(c["nxe"], c["nze"], c["nxb"], c["nzb"], c["nt"], seed=c["seed"], order=c["order"], compat=c["compat"], dx=c["dx"], dz=c["dz"])
         nx, nz, n = c["nxe"] - 2 * c["nxb"], c["nze"] - 2 * c["nzb"], c["nshots"]
         rng = np.random.default_rng(c["seed"])
         srce = (O.ricker_wavelet(c["nt"], d["dt"], 30.0) + 0.5).astype(np.float32)

@@ -198,6 +198,82 @@ def test_rtm_new_mod_shot5_full_length(new_mod):
     assert np.abs(img).max() > 0
 
 
+def _hyperbolic_gather(nx, nt, dt, sx_interior, dx, fpeak, seed):
+    """A seeded synthetic shot gather [nx][nt]: three hyperbolic Ricker events around the source column + a little noise (the
+    reference's own dobs.6 / dado_teste.bin are listed in its .MISSING_LARGE_BLOBS)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(nt, dtype=np.float32) * np.float32(dt)
+    g = np.zeros((nx, nt), np.float32)
+    off = (np.arange(nx, dtype=np.float32) - np.float32(sx_interior)) * np.float32(dx)
+    for k, (t0, amp) in enumerate(((0.35, 1.0), (0.7, -0.6), (1.1, 0.4))):
+        tt = np.sqrt(t0 * t0 + (off / (2500.0 + 400.0 * k)) ** 2)
+        x = np.pi * fpeak * (t[None, :] - tt[:, None])
+        g += (amp * (1 - 2 * x * x) * np.exp(-x * x)).astype(np.float32)
+    return g + (0.01 * rng.standard_normal(g.shape)).astype(np.float32)
+
+
+@pytest.mark.gpu
+def test_rtm_code_on_the_reference_new_mod_deck_all_six_shots(tmp_path):
+    """BASELINE config 3 as the reference runs it: `./rtm_code ./models/new_mod/input.dat` with the reference's OWN deck, velocity model
+    and six per-shot extended models (vel_ext_rnd.6, R:412-418, R:483-484), nt = 1700, on a seeded synthetic dobs.6 -- the stacked
+    dir.image against the oracle's restatement of main()'s shot loop (R:480-542), bit for bit; every shot's image is non-trivial."""
+    d = tmp_path / "models" / "new_mod"
+    d.mkdir(parents=True)
+    (tmp_path / "output").mkdir()
+    shutil.copy(os.path.join(DECKS, "new_mod.dat"), d / "input.dat")
+    shutil.copy(os.path.join(GOLDEN, "new_mod_vel_koslov.f32"), d / "vel-koslov.1")
+    vel = np.load(os.path.join(GOLDEN, "new_mod_vel_ext_rnd6.npz"))["vel"]
+    assert vel.shape == (6, 415, 295)
+    vel.tofile(d / "vel_ext_rnd.6")
+    nx, nz, nxb, nzb, nt, ns, fsx, ds = 315, 195, 50, 50, 1700, 6, 7, 60
+    dobs = np.stack([_hyperbolic_gather(nx, nt, 0.001, fsx + s * ds, 10.0, 20.0, 100 + s) for s in range(ns)])
+    dobs.tofile(d / "dobs.6")
+    r = subprocess.run([os.path.join(BIN, "rtm_code"), "./models/new_mod/input.dat"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "## nz = 195, nx = 315, nt = 1700 " in r.stdout and "** source 6, at (307,0) " in r.stdout, r.stdout
+    got = np.fromfile(tmp_path / "output" / "dir.image", np.float32).reshape(nx, nz)
+    orc = O.Oracle(8, 415, 295, nxb, nzb, nt, 0.75, 10.0, 10.0, 0.001, compat=True, omp=True)
+    srce = O.ricker_wavelet(nt, 0.001, 20.0)
+    img = np.zeros((nx, nz), np.float32)
+    for s in range(ns):
+        v2 = (vel[s] * vel[s]).astype(np.float32)
+        P, PP = orc.forward(v2, fsx + s * ds + nxb, nzb, srce)
+        imloc = orc.back(v2, P, PP, dobs[s], nzb)
+        assert np.abs(imloc).max() > 0
+        img = img + imloc
+    assert_bit_equal(got, img, "dir.image of the six-shot new_mod deck")
+    lines = (tmp_path / "image.num").read_text().splitlines()
+    assert len(lines) == ns * (1 + nx * nz) and lines[5 * (1 + nx * nz)] == "======== 5 ========"
+
+
+@pytest.mark.gpu
+def test_rtm_code_on_the_reference_marmousi_deck(tmp_path):
+    """The reference's other runnable deck (models/marmousi/input.dat: 369 x 375 model, dx = 25, dz = 8, nt = 3004, one shot, random
+    border drawn from the unseeded rand() stream, outputs in the working directory) with its own velocity model and a seeded
+    synthetic dado_teste.bin: dir.image against the oracle pipeline, bit for bit."""
+    shutil.copy(os.path.join(DECKS, "marmousi.dat"), tmp_path / "input.dat")
+    vp = np.load(os.path.join(GOLDEN, "marmousi_model_375.npz"))["vp"]
+    assert vp.shape == (369, 375)
+    vp.tofile(tmp_path / "model-375.cwp")
+    nx, nz, nb, nt = 369, 375, 40, 3004
+    dobs = _hyperbolic_gather(nx, nt, 0.001, 179, 25.0, 6.5, 7)
+    dobs.tofile(tmp_path / "dado_teste.bin")
+    r = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = np.fromfile(tmp_path / "dir.image", np.float32).reshape(nx, nz)
+    nxe, nze = nx + 2 * nb, nz + 2 * nb
+    orc = O.Oracle(8, nxe, nze, nb, nb, nt, 0.75, 25.0, 8.0, 0.001, compat=True, omp=True)
+    vpe = np.zeros((nxe, nze), np.float32)
+    vpe[nb:nb + nx, nb:nb + nz] = vp
+    O.extendvel_linear(vpe, nx, nz, nb, nb, seed=1)
+    v2 = (vpe * vpe).astype(np.float32)
+    srce = O.ricker_wavelet(nt, 0.001, 6.5)
+    P, PP = orc.forward(v2, 179 + nb, nb, srce)
+    img = orc.back(v2, P, PP, dobs, nb)
+    assert np.isfinite(img).all() and np.abs(img).max() > 0
+    assert_bit_equal(got, img, "dir.image of the marmousi deck")
+
+
 @pytest.mark.gpu
 def test_reference_signature_compat_library():
     """libfdwave_rtm_compat.so: fd_init / fd_forward / fd_back with the reference's own argument lists
