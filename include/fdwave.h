@@ -37,6 +37,7 @@ extern "C" {
 #define FDW_EHIP (-3)      /* a HIP call failed later */
 #define FDW_ENOMEM (-4)
 #define FDW_ESTATE (-5)    /* call sequence error (e.g. back() before forward() in a device-resident shot) */
+#define FDW_ECOMM (-6)     /* librccl missing, an RCCL call failed, or the ranks of an exchange disagree */
 
 typedef struct fdw_ctx fdw_ctx;
 
@@ -240,6 +241,63 @@ int fdw_model_resident(fdw_ctx *ctx, const float *vp);
 int fdw_dev_extendvel_linear(fdw_ctx *ctx, unsigned long long draw_offset, float *vel_out);
 int fdw_shot_resident(fdw_ctx *ctx, int sx, int sz, int gz, const float *srce, const float *d_obs, float *imloc, float *P, float *PP);
 int fdw_rand_stream(fdw_ctx *ctx, unsigned long long draw_offset, long long n, int *out);
+
+/* ---- multi-GPU: communicators and the slab-decomposed loops (csrc/fdw_comm.cpp, csrc/fdw_slabs.cpp) ------------------------
+ * The reference has no multi-GPU path.  The grid is decomposed along x, the slow axis, into one band of rows per
+ * rank; a rank is one GPU, driven by one process (RCCL backend) or by one host thread of a process (RCCL or local backend).
+ *
+ * fdw_comm_get_unique_id  ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to the other ranks (a file, an environment
+ *                         variable, torch.distributed ...).  librccl.so.1 is opened on first use (dlopen); FDW_ECOMM if it is missing.
+ * fdw_comm_init_rank      ncclCommInitRank on `device`: the RCCL backend, one rank per GPU.  Halo blocks travel as ncclSend / ncclRecv
+ *                         pairs inside one ncclGroupStart / ncclGroupEnd on the slab driver's communication stream (neighbours only).
+ * fdw_comm_init_local     `world` ranks inside ONE process, out[r] for the host thread that drives rank r on devices[r] (NULL: all on
+ *                         device 0).  A halo transfer is a device copy on the receiver's stream ordered by events after the sender's
+ *                         stream.  Ranks may share a device (tests and rehearsals on a one-GPU box, where RCCL refuses duplicate
+ *                         devices) or sit on different GPUs (peer copies over xGMI).  Every rank must be destroyed.
+ * fdw_comm_allreduce      one double per rank, summed (op_max = 0) or the maximum (op_max = 1); blocks the host.
+ * fdw_comm_selftest       one block sent to the OWN rank through the backend's send / receive path on a stream, and compared.
+ *
+ * fdw_slabs_create        this rank's share of the decomposition: its band of rows plus order/2 * ksteps ghost rows towards each
+ *                         neighbour (ksteps = time steps per halo exchange; 0 = chosen from the band size, the same on every rank), a
+ *                         slab context (fdw_create_slab), three streams.  Collective: every rank of `comm` calls it.  comm == NULL: one
+ *                         rank holding the whole grid on `device`.
+ * fdw_slabs_geometry      x_off = global row of local row 0, nxl = local rows (ghosts included), [own0, own1) = owned global rows,
+ *                         nbuf = field buffers fdw_slabs_dev_forward rotates over (4 where it runs four time steps per pass, else 2).
+ * fdw_slabs_dev_forward   fd_forward's loop (R:259-267) on caller-owned device arrays [nxl][fdw_pitch(fdw_slabs_ctx())]: buf[*ip], buf[*ipp]
+ *                         are the reference's (d_p, d_pp) before its first swap on entry and after the loop on return.  Halo exchanges
+ *                         included, overlapped with the interior rows; asynchronous (fdw_slabs_synchronize; fdw_slabs_stream is the
+ *                         compute stream, for events).
+ * fdw_slabs_dev_back      fd_back's loop (R:302-339): f[0], f[1] = (P, PP) of the forward pass on entry (P damped: fdw_dev_taper_finalize),
+ *                         r[0], r[1] = the receiver pair (zero on entry), d_samples[nt][nx] with row it = d_obs[.][nt-1-it], d_img
+ *                         [nxl][pitch] (owned rows meaningful).  *fswap / *rswap: roles inside the pairs exchanged (in: on entry, out: on return).
+ * fdw_slabs_shot          one shot of rtm_code's loop (R:496-520) on host arrays: every rank passes the GLOBAL v2[nxe][nze], srce[nt],
+ *                         d_obs[nx][nt]; imloc[nx][nz] (global; accumulated into) and the optional P, PP [nxe][nze] receive this rank's
+ *                         OWNED rows only.  Bit-identical to fdw_shot on the whole grid. */
+typedef struct fdw_comm fdw_comm;
+typedef struct fdw_slabs fdw_slabs;
+#define FDW_COMM_ID_BYTES 128
+int fdw_comm_get_unique_id(char id[FDW_COMM_ID_BYTES]);
+int fdw_comm_init_rank(const char id[FDW_COMM_ID_BYTES], int rank, int world, int device, fdw_comm **out);
+int fdw_comm_init_local(int world, const int *devices, fdw_comm **out /* [world] */);
+void fdw_comm_destroy(fdw_comm *comm);
+int fdw_comm_rank(const fdw_comm *comm);
+int fdw_comm_world(const fdw_comm *comm);
+int fdw_comm_device(const fdw_comm *comm);
+int fdw_comm_is_local(const fdw_comm *comm);
+int fdw_comm_allreduce(fdw_comm *comm, double *value, int op_max);
+int fdw_comm_barrier(fdw_comm *comm);
+int fdw_comm_selftest(fdw_comm *comm);
+int fdw_slabs_create(const fdw_params *prm, fdw_comm *comm, int device, int ksteps, fdw_slabs **out);
+void fdw_slabs_destroy(fdw_slabs *s);
+fdw_ctx *fdw_slabs_ctx(fdw_slabs *s);
+int fdw_slabs_geometry(const fdw_slabs *s, int *x_off, int *nxl, int *own0, int *own1, int *ksteps, int *nbuf);
+void *fdw_slabs_stream(fdw_slabs *s);
+int fdw_slabs_synchronize(fdw_slabs *s);
+int fdw_slabs_dev_forward(fdw_slabs *s, float *const *buf, const float *d_v2, const float *d_srce, int sx, int sz, int it0, int nsteps,
+                          int first_pp_twice, int *ip, int *ipp);
+int fdw_slabs_dev_back(fdw_slabs *s, float *const *f, float *const *r, const float *d_v2, const float *d_samples, int gz, float *d_img, int it0,
+                       int nsteps, int *fswap, int *rswap);
+int fdw_slabs_shot(fdw_slabs *s, const float *v2, int sx, int sz, int gz, const float *srce, const float *d_obs, float *imloc, float *P, float *PP);
 
 /* ---- tuning / introspection --------------------------------------------------------------------
  * fdw_set_tuning  xchunk = rows marched per wave (0 = auto), wz = waves of a block laid along z

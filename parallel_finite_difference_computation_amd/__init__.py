@@ -7,5 +7,7 @@ from ._lib import FdwError, LIB_PATH, MODE_FWD, MODE_PLAIN, MODE_RECV, lib  # no
 from .api import (FDWave, calc_coefs, extendvel_linear, fd_back, fd_forward, fd_init, image_laplacian, mod_extendvel,  # noqa: F401
                   mod_ricker_wavelet, mod_taper_tables, ricker_wavelet, srand, taper_tables)
 
-__all__ = ["FDWave", "FdwError", "calc_coefs", "ricker_wavelet", "taper_tables", "extendvel_linear", "srand",
+from .slabs import Comm, Slabs, run_ranks  # noqa: F401,E402
+
+__all__ = ["Comm", "Slabs", "run_ranks", "FDWave", "FdwError", "calc_coefs", "ricker_wavelet", "taper_tables", "extendvel_linear", "srand",
            "fd_init", "fd_forward", "fd_back", "mod_extendvel", "mod_ricker_wavelet", "mod_taper_tables", "image_laplacian", "lib", "LIB_PATH", "MODE_FWD", "MODE_PLAIN", "MODE_RECV"]

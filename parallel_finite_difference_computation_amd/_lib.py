@@ -70,6 +70,26 @@ SIGNATURES = [
     ("fdw_dev_laplacian", C.c_int, [vp, vp, vp, vp]),
     ("fdw_upload_field", C.c_int, [vp, vp, f32p]),
     ("fdw_download_field", C.c_int, [vp, f32p, vp]),
+    ("fdw_comm_get_unique_id", C.c_int, [C.c_char_p]),
+    ("fdw_comm_init_rank", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    ("fdw_comm_init_local", C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]),
+    ("fdw_comm_destroy", None, [vp]),
+    ("fdw_comm_rank", C.c_int, [vp]),
+    ("fdw_comm_world", C.c_int, [vp]),
+    ("fdw_comm_device", C.c_int, [vp]),
+    ("fdw_comm_is_local", C.c_int, [vp]),
+    ("fdw_comm_allreduce", C.c_int, [vp, C.POINTER(C.c_double), C.c_int]),
+    ("fdw_comm_barrier", C.c_int, [vp]),
+    ("fdw_comm_selftest", C.c_int, [vp]),
+    ("fdw_slabs_create", C.c_int, [C.POINTER(Params), vp, C.c_int, C.c_int, C.POINTER(vp)]),
+    ("fdw_slabs_destroy", None, [vp]),
+    ("fdw_slabs_ctx", vp, [vp]),
+    ("fdw_slabs_geometry", C.c_int, [vp] + [C.POINTER(C.c_int)] * 6),
+    ("fdw_slabs_stream", vp, [vp]),
+    ("fdw_slabs_synchronize", C.c_int, [vp]),
+    ("fdw_slabs_dev_forward", C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("fdw_slabs_dev_back", C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), vp, vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("fdw_slabs_shot", C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, vp, vp]),
     ("fdw_set_tuning", C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("fdw_get_tables", C.c_int, [vp, vp, vp, vp, vp]),
     ("fdw_get_extents", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -16,6 +16,7 @@
 #include <new>
 #include <vector>
 
+#include "fdw_internal.h"
 #include "fdw_kernels.h"
 #include "fdwave.h"
 
@@ -26,7 +27,7 @@ using namespace fdw;
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char* fmt, ...)
+int fdw_fail(int code, const char* fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -34,6 +35,7 @@ static int fail(int code, const char* fmt, ...)
     va_end(ap);
     return code;
 }
+#define fail fdw_fail
 
 #define HIP_TRY(call)                                                                                     \
     do {                                                                                                  \
