@@ -320,6 +320,181 @@ def run_rtm_workload(args):
     print(json.dumps(out), flush=True)
 
 
+def run_rtm_slab_workload(args):
+    """`--workload rtm-slab`: BASELINE.json's fourth configuration -- the RTM loops under domain decomposition: ONE shot on an n x n grid split
+    into x slabs over the N ranks: K forward steps (fd_forward, fd-code.cu:259-267), the snapshot hand-over, then K backward iterations
+    with source-field reconstruction, receiver injection and imaging (fd_back, fd-code.cu:302-339), halo exchanges of two / four fields
+    overlapped with the interior rows.  A "step" is one time index of the shot = three field updates; value = 3 n^2 K / wall.
+    N = 1 runs the same driver on one slab (the whole grid).  --backend nccl: everything inside libfdwave.so over RCCL (fdw_slabs_*);
+    --backend gloo: the Python harness (decomp.SlabForward / SlabBack), ranks may share one GPU.  The image gathered from the slabs is
+    compared bitwise with a single-domain run on rank 0 unless --no-check."""
+    from parallel_finite_difference_computation_amd.decomp import HipSlabBackStepper, SlabBack, slab_bounds
+    rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        if world == 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if args.backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, K, W = args.size, args.steps, args.warmup
+    nt = max(K, W)
+    nx = n - 2 * NB
+    gz = NB + 3
+    sx, sz = n // 2, NB + 2
+    c_driver = args.backend == "nccl"
+    mk = dict(compat=False)
+    srce = torch.from_numpy(F.ricker_wavelet(nt, DT, FPEAK)).to(dev)
+    gsmp = torch.Generator(device=dev)
+    gsmp.manual_seed(0x5EED0005)
+    samples = torch.randn((nt, nx), device=dev, generator=gsmp)
+
+    def make_rank(comm_, geom_world, geom_rank):
+        """Driver state of one rank: fields with the decomposition-independent noise start, v2, image."""
+        if c_driver:
+            sl = F.Slabs(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, comm=comm_, compat=False, ksteps=args.ksteps, device=local_rank)
+            g = SlabGeometry(geom_rank, geom_world, n, ORDER // 2, sl.ksteps)
+            pitch, nbuf, ctx = sl.pitch, sl.nbuf, None
+        else:
+            k = args.ksteps if args.ksteps > 0 else 4
+            g = SlabGeometry(geom_rank, geom_world, n, ORDER // 2, k if geom_world > 1 else 1)
+            ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank, slab=(g.x_off, g.nxl) if geom_world > 1 else None)
+            sl, pitch, nbuf = None, ctx.pitch, 2
+        st = dict(sl=sl, ctx=ctx, g=g, pitch=pitch)
+        st["fld"] = [torch.zeros((g.nxl, pitch), device=dev) for _ in range(nbuf + 2)]          # forward buffers + the receiver pair
+        gen = torch.Generator(device=dev)
+        for f_, seed in ((st["fld"][0], 0x5EED0001), (st["fld"][1], 0x5EED0002)):
+            gen.manual_seed(seed)
+            f_[:, :n] = (1e-3 * torch.randn((n, 64), device=dev, generator=gen))[g.x_off:g.x_off + g.nxl].repeat(1, n // 64)
+        st["v2"] = torch.zeros((g.nxl, pitch), device=dev)
+        st["v2"][:, :n] = synthetic_velocity_rows(n, g.x_off, g.nxl, dev)
+        st["img"] = torch.zeros((g.nxl, pitch), device=dev)
+        st["nbuf"], st["ip"], st["ipp"] = nbuf, 0, 1
+        if not c_driver:
+            st["fw"] = SlabForward(g, HipSlabStepper(ctx), st["fld"][:2], st["v2"], srce, sx, sz, overlap=not args.no_overlap)
+        return st
+
+    def shot(st, nsteps):
+        """forward nsteps, snapshot hand-over, backward nsteps with imaging (enqueue; the caller synchronises)."""
+        fld, rcv = st["fld"], st["fld"][st["nbuf"]:]
+        if c_driver:
+            sl = st["sl"]
+            st["ip"], st["ipp"] = sl.dev_forward([f_.data_ptr() for f_ in fld[:st["nbuf"]]], st["v2"].data_ptr(), srce.data_ptr(), sx, sz, 0, nsteps, True,
+                                                 st["ip"], st["ipp"])
+            sl.taper_finalize(fld[st["ip"]].data_ptr())                               # the damped d_p the reference hands over (R:285)
+            with torch.cuda.stream(torch.cuda.ExternalStream(sl.stream)):
+                rcv[0].zero_()
+                rcv[1].zero_()                                                        # R:513-514
+            sl.dev_back([fld[st["ip"]].data_ptr(), fld[st["ipp"]].data_ptr()], [r_.data_ptr() for r_ in rcv], st["v2"].data_ptr(), samples.data_ptr(),
+                        gz, st["img"].data_ptr(), 0, nsteps)
+        else:
+            fw = st["fw"]
+            fw.it = 0
+            fw.run(nsteps)
+            fw.synchronize()
+            st["ctx"].dev_taper_finalize(fw.d_p.data_ptr())
+            rcv[0].zero_()
+            rcv[1].zero_()
+            torch.cuda.synchronize()
+            bk = SlabBack(st["g"], HipSlabBackStepper(st["ctx"]), (fw.d_p, fw.d_pp), rcv, st["v2"], samples, gz, st["img"], nt, overlap=not args.no_overlap)
+            bk.run(nsteps)
+            bk.synchronize()
+            st["bk"] = bk
+
+    def sync(st):
+        if c_driver:
+            st["sl"].synchronize()
+        torch.cuda.synchronize()
+
+    comm = None
+    if c_driver and world > 1:
+        uid = [F.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = F.Comm.rccl(uid[0], rank, world, local_rank)
+    me = make_rank(comm, world, rank)
+    torch.cuda.synchronize()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    shot(me, W)
+    sync(me)
+
+    def window():
+        t0 = time.perf_counter()
+        shot(me, K)
+        sync(me)
+        return (time.perf_counter() - t0) * 1e3
+
+    wall, _, nwin = timed_windows(window, sync_all, world, dev)
+    g = me["g"]
+    img_own = me["img"][g.g_lo:g.nxl - g.g_hi, :n]
+    finite = bool(torch.isfinite(img_own).all().item())
+    nonzero = float(img_own.abs().max().item()) > 0.0
+    if world > 1:
+        f = torch.tensor([1.0 if finite else 0.0, 1.0 if nonzero else 0.0])
+        dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        nonzero = bool(f[1].item() > 0.5)
+        f2 = torch.tensor([1.0 if finite else 0.0])
+        dist.all_reduce(f2, op=dist.ReduceOp.MIN)
+        finite = bool(f2.item() > 0.5)
+    check = None
+    if world > 1 and not args.no_check:
+        own = img_own.contiguous().cpu()
+        if rank == 0:
+            parts = [torch.empty(((b1 - b0), n)) for (b0, b1) in slab_bounds(n, world)]
+            parts[0].copy_(own)
+            for r in range(1, world):
+                dist.recv(parts[r], src=r)
+            full = torch.cat(parts).to(dev)
+            ref = make_rank(None, 1, 0)                    # the same driver on ONE slab = the whole grid, same sequence of shots
+            shot(ref, W)
+            sync(ref)
+            for _ in range(nwin):
+                shot(ref, K)
+                sync(ref)
+            same = bool(torch.equal(full, ref["img"][:, :n]))
+            print(f"[check] decomposed image ({world} slabs) == single domain, bitwise: {same}", file=sys.stderr, flush=True)
+            check = "image bitwise equal to a single-domain run of the same shots" if same else "image DIFFERS from the single-domain run"
+            if not same:
+                sys.exit("bench: the decomposed image differs from the single-domain image")
+        else:
+            dist.send(own, dst=0)
+    if rank == 0:
+        upd = 3.0 * n * n * K
+        bytes_min = (16.0 + 16.0 + 28.0) * n * n * K         # forward step 16 B/point + backward iteration 44 B/point (SURVEY.md 8d: 40 + the image read)
+        out = {"metric": "Gpoints/s (stencil updates) + achieved HBM GB/s vs peak", "value": round(upd / wall / 1e9, 3), "unit": "Gpoints/s", "n_gpus": world,
+               "steps": K, "warmup": W, "ms_per_step": round(wall * 1e3 / K, 6), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic (seeded noise wavefield and gather)",
+               "config": {"workload": f"RTM domain decomposition: one shot on a {n}x{n} fp32 grid in {world} x-slab(s): {K} forward steps + {K} backward iterations "
+                                      f"with imaging, {me['g'].ksteps if world > 1 else 0} steps per halo exchange", "grid": [n, n], "order": ORDER,
+                          "parallelism": f"slab{world}" if world > 1 else "single"},
+               "result_finite_nonzero": finite and nonzero,
+               "halo_exchange": ("RCCL ncclSend/ncclRecv groups issued by libfdwave.so on the communication stream" if c_driver else "torch.distributed gloo (single-GPU rehearsal harness)") if world > 1 else None,
+               "decomposition_check": check,
+               "timing": {"windows": nwin, "window_steps": K, "statistic": "median window (barrier + synchronize on both sides, max over ranks)"},
+               "roofline": {"bound": "hbm", "achieved": round(bytes_min / wall / 1e9, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                            "frac": round(bytes_min / wall / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None,
+                            "basis": "algorithmic bytes of the one-step kernels: forward step 16 B/point, backward iteration 44 B/point (two field updates + image), owned rows only"}}
+        print(json.dumps(out), flush=True)
+    if c_driver:
+        me["sl"].close()
+        if comm is not None:
+            comm.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if not (finite and nonzero):
+        sys.exit("bench: image is not finite / all zero")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -329,16 +504,22 @@ def main():
     ap.add_argument("--ksteps", type=int, default=0, help="time steps per halo exchange (N > 1); 0 = auto")
     ap.add_argument("--pipe", choices=("auto", "on", "off"), default="auto",
                     help="N > 1: four-steps-per-pass wave-pipeline kernel inside the slabs (auto = where the library would pick it)")
-    ap.add_argument("--workload", choices=("forward", "model", "rtm", "stencil"), default="forward",
+    ap.add_argument("--workload", choices=("forward", "model", "rtm", "stencil", "rtm-slab"), default="forward",
                     help="forward: the headline fused forward step of rtm_code (default); model: the forward-modelling producer; "
                          "rtm: whole RTM shots on the reference's new_mod deck size (both N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for single-GPU rehearsals)")
-    ap.add_argument("--check", action="store_true", help="N > 1: compare the decomposed result with a single-domain run on rank 0 (small sizes)")
+    ap.add_argument("--backend", default="nccl", help="N > 1: nccl = halo exchange over RCCL inside libfdwave.so, one rank per GPU (default); "
+                                                      "gloo = the Python harness over torch.distributed gloo, ranks may share one GPU (rehearsals)")
+    ap.add_argument("--check", action="store_true", help="N > 1: compare the decomposed result with a single-domain run on rank 0 (default with --backend nccl)")
+    ap.add_argument("--no-check", action="store_true", help="N > 1, --backend nccl: skip that comparison")
     ap.add_argument("--init", choices=["noise", "rest"], default="noise",
                     help="initial wavefield: seeded noise (default; every cache line carries real data) or at rest (zeros + source)")
     args = ap.parse_args()
+    if args.workload == "rtm-slab":
+        if not torch.cuda.is_available():
+            sys.exit("bench: no GPU visible (the product has no CPU path)")
+        return run_rtm_slab_workload(args)
     if args.workload != "forward":
         if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
             sys.exit(f"bench --workload {args.workload} runs on one GPU")
@@ -362,37 +543,53 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        # control plane (barriers, the max over ranks of the window time, gathering the slabs for the check): a gloo group on the host.
+        # The data plane -- the halo rows -- travels inside libfdwave.so over RCCL / xGMI (--backend nccl, the default) or, for rehearsals
+        # of several ranks on ONE GPU (--backend gloo; RCCL refuses duplicate devices), through the Python harness decomp.SlabForward.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n, K, W = args.size, args.steps, args.warmup
     nt = K + W
-    if world > 1 and args.ksteps <= 0:
-        # One exchange costs the host a few hundred us of Python/RCCL enqueue whatever its size, so make a
-        # cycle last >= ~500 us of GPU time: k = 500 us / (slab points / ~350 Gpt/s), clamped to [2, 16].
-        # Redundant ghost work is h*(k-1)/2 rows per side per step (5.9 % of a 1024-row slab at k = 16).
-        t_step_us = (n / world) * n / 350e9 * 1e6
-        args.ksteps = int(max(2, min(16, -(-500.0 // t_step_us))))
-    use_pipe = False
-    if world > 1 and args.pipe != "off":
-        # decide on the slab size every rank has in common (all ranks must take the same path): rows of the thinnest slab
-        probe = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank, slab=(0, n // world))
-        use_pipe = args.pipe == "on" or probe.steps_per_pass() == 4
-        del probe
-        if use_pipe:
-            args.ksteps = max(4, min(16, 4 * -(-args.ksteps // 4)))      # whole passes of four steps
-    geom = SlabGeometry(rank, world, n, ORDER // 2, args.ksteps if world > 1 else 1)
-    ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank,
-                   slab=(geom.x_off, geom.nxl) if world > 1 else None)
-    if os.environ.get("FDW_XCHUNK"):      # tuning experiments only
-        ctx.set_tuning(xchunk=int(os.environ["FDW_XCHUNK"]))
-    pitch = ctx.pitch
-    v2 = torch.zeros((geom.nxl, pitch), device=dev)
-    v2[:, :n] = synthetic_velocity_rows(n, geom.x_off, geom.nxl, dev)
     srce = torch.from_numpy(F.ricker_wavelet(nt, DT, FPEAK)).to(dev)
     sx, sz = n // 2, n // 2
+    c_driver = (world > 1 and args.backend == "nccl") or os.environ.get("FDW_FORCE_SLAB_DRIVER") == "c"      # the latter: the multi-GPU code path on one rank (tests)
+    slabs = comm = None
+    use_pipe = False
+    if c_driver:
+        uid = [F.Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        comm = F.Comm.rccl(uid[0], rank, world, local_rank)                  # ncclCommInitRank: one rank per GPU
+        if args.pipe != "auto":
+            os.environ["FDW_SLAB_PIPE"] = "1" if args.pipe == "on" else "0"
+        if args.no_overlap:
+            os.environ["FDW_SLAB_NO_OVERLAP"] = "1"
+        slabs = F.Slabs(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, comm=comm, compat=False, ksteps=args.ksteps)
+        args.ksteps, use_pipe = slabs.ksteps, slabs.nbuf == 4
+        geom = SlabGeometry(rank, world, n, ORDER // 2, slabs.ksteps)
+        assert (geom.x_off, geom.nxl, geom.o0, geom.o1) == (slabs.x_off, slabs.nxl, slabs.own0, slabs.own1)
+        ctx, pitch = None, slabs.pitch
+    else:
+        if world > 1 and args.ksteps <= 0:
+            # One exchange costs the host a few hundred us of Python enqueue whatever its size, so make a
+            # cycle last >= ~500 us of GPU time: k = 500 us / (slab points / ~350 Gpt/s), clamped to [2, 16].
+            t_step_us = (n / world) * n / 350e9 * 1e6
+            args.ksteps = int(max(2, min(16, -(-500.0 // t_step_us))))
+        if world > 1 and args.pipe != "off":
+            # decide on the slab size every rank has in common (all ranks must take the same path): rows of the thinnest slab
+            probe = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank, slab=(0, n // world))
+            use_pipe = args.pipe == "on" or probe.steps_per_pass() == 4
+            del probe
+            if use_pipe:
+                args.ksteps = max(4, min(16, 4 * -(-args.ksteps // 4)))      # whole passes of four steps
+        geom = SlabGeometry(rank, world, n, ORDER // 2, args.ksteps if world > 1 else 1)
+        ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank,
+                       slab=(geom.x_off, geom.nxl) if world > 1 else None)
+        if os.environ.get("FDW_XCHUNK"):      # tuning experiments only
+            ctx.set_tuning(xchunk=int(os.environ["FDW_XCHUNK"]))
+        pitch = ctx.pitch
+    v2 = torch.zeros((geom.nxl, pitch), device=dev)
+    v2[:, :n] = synthetic_velocity_rows(n, geom.x_off, geom.nxl, dev)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -400,7 +597,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if world == 1 and not os.environ.get("FDW_FORCE_SLAB_DRIVER"):
+    def slab_noise_fields(count):
+        """`count` local fields; the first two carry the same GLOBAL noise field on every decomposition (seeded per global row)."""
+        fl = [torch.zeros((geom.nxl, pitch), device=dev) for _ in range(count)]
+        if args.init == "noise":
+            g = torch.Generator(device=dev)
+            for f_, seed in ((fl[0], 0x5EED0001), (fl[1], 0x5EED0002)):
+                g.manual_seed(seed)
+                full_rows = 1e-3 * torch.randn((n, 64), device=dev, generator=g)      # cheap, decomposition-independent pattern
+                f_[:, :n] = full_rows[geom.x_off:geom.x_off + geom.nxl].repeat(1, n // 64)
+        return fl
+
+    if world == 1 and not c_driver and not os.environ.get("FDW_FORCE_SLAB_DRIVER"):
         # One GPU: the library's forward loop over four rotating buffers (fdw_dev_steps2): pairs of time steps go
         # through the two-step kernel (temporal blocking) where it pays, everything enqueued by ONE library call.
         skew = int(os.environ.get("FDW_ALLOC_SKEW", "0"))     # tuning experiments only: bytes of padding between the field buffers
@@ -438,16 +646,30 @@ def main():
 
         wall, dev_ms, nwin = timed_windows(window, sync_all, world, dev)
         newest = bufs[roles["ipp"]]
+    elif c_driver:
+        # N GPUs, one rank each: the whole K-step window -- passes, boundary strips, halo exchange over RCCL on the communication stream,
+        # interior rows beside the transfer -- is enqueued by ONE call into the C library (fdw_slabs_dev_forward)
+        fields = slab_noise_fields(slabs.nbuf)
+        ptrs = [f_.data_ptr() for f_ in fields]
+        roles = {"ip": 0, "ipp": 1}
+
+        def run(it0, nsteps):
+            roles["ip"], roles["ipp"] = slabs.dev_forward(ptrs, v2.data_ptr(), srce.data_ptr(), sx, sz, it0, nsteps, it0 > 0, roles["ip"], roles["ipp"])
+
+        torch.cuda.synchronize()
+        run(0, W)
+        slabs.synchronize()
+
+        def window():
+            t0 = time.perf_counter()
+            run(W, K)
+            slabs.synchronize()
+            return (time.perf_counter() - t0) * 1e3
+
+        wall, dev_ms, nwin = timed_windows(window, sync_all, world, dev)
+        newest = fields[roles["ipp"]][geom.g_lo:geom.nxl - geom.g_hi]
     else:
-        a = torch.zeros((geom.nxl, pitch), device=dev)
-        b = torch.zeros((geom.nxl, pitch), device=dev)
-        if args.init == "noise":   # the same global noise field on every decomposition: seeded per global row block
-            g = torch.Generator(device=dev)
-            for f_, seed in ((a, 0x5EED0001), (b, 0x5EED0002)):
-                g.manual_seed(seed)
-                full_rows = 1e-3 * torch.randn((n, 64), device=dev, generator=g)      # cheap, decomposition-independent pattern
-                f_[:, :n] = full_rows[geom.x_off:geom.x_off + geom.nxl].repeat(1, n // 64)
-        fields = (a, b) + ((torch.zeros_like(a), torch.zeros_like(a)) if use_pipe else ())
+        fields = slab_noise_fields(4 if use_pipe else 2)
         fw = SlabForward(geom, HipSlabStepper(ctx), fields, v2, srce, sx, sz, overlap=not args.no_overlap, pipe_ctx=ctx if use_pipe else None)
         torch.cuda.synchronize()       # fields were filled on torch's default stream; the driver's streams do not wait for it
         fw.run(W)
@@ -468,20 +690,23 @@ def main():
         newest = fw.owned(fw.d_pp)
     finite = bool(torch.isfinite(newest).all().item()) and float(newest.abs().max().item()) > 0.0
     if world > 1:
-        f = torch.tensor([1.0 if finite else 0.0], device=dev)
+        f = torch.tensor([1.0 if finite else 0.0])
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
         finite = bool(f.item() > 0.5)
 
-    if world > 1 and args.check:
-        own = newest[:, :n].contiguous()
-        parts = [torch.empty(((b1 - b0), n), device=dev) for (b0, b1) in __import__("parallel_finite_difference_computation_amd.decomp", fromlist=["slab_bounds"]).slab_bounds(n, world)] if rank == 0 else None
+    check = None
+    if world > 1 and (args.check or (c_driver and not args.no_check)):
+        # the decomposed field against a single-domain run of the same step sequence (warm-up, then `nwin` windows that replay the
+        # source samples W .. W+K-1) on rank 0, bitwise: a halo that arrives late or not at all cannot hide behind a plausible number
+        own = newest[:, :n].contiguous().cpu()
+        from parallel_finite_difference_computation_amd.decomp import slab_bounds
         if rank == 0:
+            parts = [torch.empty(((b1 - b0), n)) for (b0, b1) in slab_bounds(n, world)]
             parts[0].copy_(own)
             for r in range(1, world):
                 dist.recv(parts[r], src=r)
-            full = torch.cat(parts)
+            full = torch.cat(parts).to(dev)
             ref_ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank)
-            ref_ctx.set_tuning(two_step=-1)
             rb = [torch.zeros((n, ref_ctx.pitch), device=dev) for _ in range(4)]
             if args.init == "noise":
                 g = torch.Generator(device=dev)
@@ -490,12 +715,17 @@ def main():
                     f_[:, :n] = (1e-3 * torch.randn((n, 64), device=dev, generator=g)).repeat(1, n // 64)
             rv2 = torch.zeros((n, ref_ctx.pitch), device=dev)
             rv2[:, :n] = synthetic_velocity_rows(n, 0, n, dev)
-            ip, ipp = ref_ctx.dev_steps2([b_.data_ptr() for b_ in rb], rv2.data_ptr(), srce.data_ptr(), sx, sz, 0, W + K, False, 0, 1, stream=None)
+            rptrs = [b_.data_ptr() for b_ in rb]
+            torch.cuda.synchronize()
+            ip, ipp = ref_ctx.dev_steps2(rptrs, rv2.data_ptr(), srce.data_ptr(), sx, sz, 0, W, False, 0, 1, stream=None)
+            for _ in range(nwin):
+                ip, ipp = ref_ctx.dev_steps2(rptrs, rv2.data_ptr(), srce.data_ptr(), sx, sz, W, K, True, ip, ipp, stream=None)
             torch.cuda.synchronize()
             same = bool(torch.equal(full, rb[ipp][:, :n]))
             print(f"[check] decomposed ({world} slabs) == single domain, bitwise: {same}", file=sys.stderr, flush=True)
+            check = "bitwise equal to a single-domain run of the same step sequence" if same else "DIFFERS from the single-domain run"
             if not same:
-                sys.exit("bench --check: decomposed result differs from the single-domain result")
+                sys.exit("bench: the decomposed result differs from the single-domain result")
         else:
             dist.send(own, dst=0)
     if rank == 0:
@@ -514,11 +744,15 @@ def main():
                        "grid": [n, n], "order": ORDER, "parallelism": f"slab{world}" if world > 1 else "single"},
             "result_finite_nonzero": finite,
         }
+        if world > 1:
+            out["halo_exchange"] = ("RCCL ncclSend/ncclRecv groups issued by libfdwave.so on the communication stream" if c_driver
+                                    else f"torch.distributed {args.backend} (single-GPU rehearsal harness)")
+            out["decomposition_check"] = check
         out["timing"] = {"windows": nwin, "window_steps": K, "statistic": "median window (each bracketed by barrier + synchronize, max over ranks)",
                          "measured_seconds_min": MIN_TIMED_SECONDS}
         model_note = ("SURVEY.md 8(d)'s one-pass-per-step byte model (16 B/point/step x the steps one launch advances); a temporally blocked launch "
                       "moves a fraction of it, so this ratio can exceed 1 -- it is a throughput figure in bytes, NOT a roofline fraction")
-        if world == 1:
+        if world == 1 and ctx is not None:
             steps_per_launch = ctx.steps_per_pass()          # 4: wave pipeline, 2: two-step kernel, 1: one-step kernel
             rem = K % steps_per_launch
             launches = K // steps_per_launch + (rem // 2 + rem % 2 if ctx.two_step_active() else rem)
@@ -556,6 +790,9 @@ def main():
                                "algorithmic_16B_model": {"bytes": algo, "achieved": round(algo / wall / 1e9, 1),
                                                          "ratio_to_peak": round(algo / wall / 1e9 / (HBM_PEAK_GBS * world), 4), "note": model_note}}
         print(json.dumps(out), flush=True)
+    if slabs is not None:
+        slabs.close()
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
     if not finite:

@@ -254,6 +254,8 @@ int fdw_rand_stream(fdw_ctx *ctx, unsigned long long draw_offset, long long n, i
  *                         device 0).  A halo transfer is a device copy on the receiver's stream ordered by events after the sender's
  *                         stream.  Ranks may share a device (tests and rehearsals on a one-GPU box, where RCCL refuses duplicate
  *                         devices) or sit on different GPUs (peer copies over xGMI).  Every rank must be destroyed.
+ * fdw_comm_init_stub      rank `rank` of a world whose other ranks do not exist: exchanges move nothing.  TIMING EXPERIMENTS ONLY (what
+ *                         one rank of an N-way decomposition costs without its links: scripts/probe_slabs_c.py); results are wrong.
  * fdw_comm_allreduce      one double per rank, summed (op_max = 0) or the maximum (op_max = 1); blocks the host.
  * fdw_comm_selftest       one block sent to the OWN rank through the backend's send / receive path on a stream, and compared.
  *
@@ -279,6 +281,7 @@ typedef struct fdw_slabs fdw_slabs;
 int fdw_comm_get_unique_id(char id[FDW_COMM_ID_BYTES]);
 int fdw_comm_init_rank(const char id[FDW_COMM_ID_BYTES], int rank, int world, int device, fdw_comm **out);
 int fdw_comm_init_local(int world, const int *devices, fdw_comm **out /* [world] */);
+int fdw_comm_init_stub(int rank, int world, int device, fdw_comm **out);
 void fdw_comm_destroy(fdw_comm *comm);
 int fdw_comm_rank(const fdw_comm *comm);
 int fdw_comm_world(const fdw_comm *comm);

@@ -73,6 +73,7 @@ SIGNATURES = [
     ("fdw_comm_get_unique_id", C.c_int, [C.c_char_p]),
     ("fdw_comm_init_rank", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     ("fdw_comm_init_local", C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]),
+    ("fdw_comm_init_stub", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     ("fdw_comm_destroy", None, [vp]),
     ("fdw_comm_rank", C.c_int, [vp]),
     ("fdw_comm_world", C.c_int, [vp]),

@@ -70,7 +70,7 @@ struct fdw_ctx {
     float *d_taperz = nullptr, *d_txfac = nullptr, *d_gcx = nullptr, *d_gcz = nullptr;
     hipStream_t stream = nullptr;
     // lazily allocated work buffers of the host-array API
-    float* fld[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* fld[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // 8, 9: source-field levels of a backward pipeline pass
     float *d_v2 = nullptr, *d_img = nullptr, *d_srce = nullptr, *d_dobs = nullptr;
     size_t srce_cap = 0, dobs_cap = 0;
     // tuning
@@ -90,6 +90,7 @@ struct fdw_ctx {
     float* d_raw = nullptr;      // gathers as the caller holds them ([shot][nx][nt]) before the transposition on the device
     size_t raw_cap = 0;
     int no_fused_back = 0;   // experiments / tests: backward iterations as two launches (source step, receiver step) -- FDW_NO_FUSED_BACK=1
+    int no_back_pipe = 0;    // experiments / tests: no wave-pipeline passes in the backward loop -- FDW_NO_BACK_PIPE=1
 };
 
 static size_t field_elems(const fdw_ctx* c) { return (size_t)c->nxl * (size_t)c->pitch; }
@@ -195,6 +196,7 @@ extern "C" int fdw_create_slab(const fdw_params* prm, const fdw_slab* slab, int 
     c->nz = prm->nze - 2 * prm->nzb;
     c->pitch = ((prm->nze + 63) / 64) * 64;  // 256-B aligned rows: every lane's float4 is aligned
     if (const char* nf = getenv("FDW_NO_FUSED_BACK")) c->no_fused_back = atoi(nf);
+    if (const char* nf = getenv("FDW_NO_BACK_PIPE")) c->no_back_pipe = atoi(nf);
     if (const char* pad = getenv("FDW_PITCH_PAD")) {   // experiment knob: extra floats per row (multiple of 4)
         const int extra = atoi(pad);
         if (extra > 0 && extra % 4 == 0) c->pitch += extra;
@@ -308,7 +310,7 @@ extern "C" void fdw_destroy(fdw_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     float* bufs[] = {c->d_taperz, c->d_txfac, c->d_gcx, c->d_gcz, c->fld[0], c->fld[1], c->fld[2], c->fld[3],
-                     c->fld[4], c->fld[5], c->fld[6], c->fld[7], c->d_v2, c->d_img, c->d_srce, c->d_dobs, c->d_rec,
+                     c->fld[4], c->fld[5], c->fld[6], c->fld[7], c->fld[8], c->fld[9], c->d_v2, c->d_img, c->d_srce, c->d_dobs, c->d_rec,
                      c->d_vp, c->d_vpe, (float*)c->d_draws, (float*)c->d_jump, c->bfld[0], c->bfld[1], c->bfld[2], c->bfld[3],
                      c->bfld[4], c->bfld[5], c->bfld[6], c->bfld[7], c->b_v2, c->b_img, c->b_dobs, c->d_raw};
     for (float* b : bufs)
@@ -607,15 +609,25 @@ static bool pipe_pays(const fdw_ctx* c)
 
 // FWD: d_inj -> kPipeSteps source samples srce[it .. it+kPipeSteps-1]; PLAIN: no taper, no injection.
 // d_out1 = u^{n+kPipeSteps-1}, d_out2 = u^{n+kPipeSteps}.
+struct StepnBack {      // the two passes of the backward loop (Step2Args: lvl0, lvl1, plev, img, inj_stride)
+    float *lvl0 = nullptr, *lvl1 = nullptr;       // PLAIN_ALL: where waves 0 and 1 store their levels
+    const float* plev[kPipeSteps] = {};           // RECV: the source field of iterations it .. it+3
+    float* img = nullptr;
+    int inj_stride = 0;                           // RECV: floats between the sample rows of consecutive iterations
+};
 struct RowRanges {      // rows the pass produces: [r0, r1) and optionally [r0b, r1b); r1 < 0 = all rows the reference time-steps
     int r0 = 0, r1 = -1, r0b = 0, r1b = 0, xchunk = 0;
 };
 static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp, const float* d_v2, float* d_out1, float* d_out2, int pp_twice,
                       const float* d_inj, int inj_x_global, int inj_z, hipStream_t s, const RowRanges& rr = RowRanges{}, float* d_rec = nullptr,
-                      int rec_z = 0)
+                      int rec_z = 0, const StepnBack* bk = nullptr)
 {
     if (c->h != kMaxFastHalfOrder) return fail(FDW_EINVAL, "stepn: the pipelined kernel is built for order 8 only");
-    if (mode != FDW_MODE_FWD && mode != FDW_MODE_PLAIN && mode != FDW_MODE_MOD) return fail(FDW_EINVAL, "stepn: FWD, PLAIN or MOD only");
+    if (mode != FDW_MODE_FWD && mode != FDW_MODE_PLAIN && mode != FDW_MODE_MOD && mode != FDW_MODE_PLAIN_ALL && mode != FDW_MODE_RECV)
+        return fail(FDW_EINVAL, "stepn: FWD, PLAIN, PLAIN_ALL, RECV or MOD only");
+    if ((mode == FDW_MODE_PLAIN_ALL && (!bk || !bk->lvl0 || !bk->lvl1)) ||
+        (mode == FDW_MODE_RECV && (!bk || !bk->img || !d_inj || !bk->plev[0] || !bk->plev[1] || !bk->plev[2] || !bk->plev[3])))
+        return fail(FDW_EINVAL, "stepn: the backward passes need their level buffers / source fields, samples and image");
     if ((mode == FDW_MODE_MOD) != (c->prm.dialect == FDW_DIALECT_MOD)) return fail(FDW_ESTATE, "stepn: mode %d does not belong to dialect %d", mode, c->prm.dialect);
     if (!d_p || !d_pp || !d_v2 || !d_out1 || !d_out2) return fail(FDW_EINVAL, "stepn: NULL buffer");
     if (d_out1 == d_p || d_out1 == d_pp || d_out2 == d_p || d_out2 == d_pp || d_out1 == d_out2)
@@ -639,6 +651,23 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
         a.inj_x = inj_x_global - c->slab.x_off;
         if (a.inj_x >= c->upd_x1 && a.inj_x < c->nxl)
             return fail(FDW_EINVAL, "stepn: source row %d lies in rows the reference never time-steps (>= %d)", inj_x_global, c->xlim);
+    }
+    if (mode == FDW_MODE_PLAIN_ALL) {
+        a.lvl0 = bk->lvl0; a.lvl1 = bk->lvl1;
+        for (float* o : {d_out1, d_out2}) if (bk->lvl0 == o || bk->lvl1 == o || bk->lvl0 == bk->lvl1 || bk->lvl0 == d_p || bk->lvl0 == d_pp || bk->lvl1 == d_p || bk->lvl1 == d_pp)
+            return fail(FDW_EINVAL, "stepn: level buffers must not alias the inputs or outputs");
+    }
+    if (mode == FDW_MODE_RECV) {
+        if (inj_z < 0 || inj_z >= c->prm.nze) return fail(FDW_EINVAL, "stepn: receiver depth %d outside the grid", inj_z);
+        const int g0 = c->prm.nxb, g1 = c->prm.nxb + std::min(c->nx, c->xlim);       // receivers on interior rows (R:126-129)
+        const int l0 = std::max(g0 - c->slab.x_off, 0), l1 = std::min(g1 - c->slab.x_off, c->nxl);
+        a.inj_x = l0;
+        a.inj_n = std::max(0, l1 - l0);
+        a.inj = d_inj + (l0 + c->slab.x_off - g0);
+        a.inj_stride = bk->inj_stride;
+        a.img = bk->img;
+        a.img_z1 = c->prm.nzb + std::min(c->nz, c->zlim);
+        for (int i = 0; i < kPipeSteps; i++) a.plev[i] = bk->plev[i];
     }
     if (mode == FDW_MODE_MOD) {
         if (d_inj) {
@@ -677,6 +706,10 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
         const size_t off = (size_t)c->upd_x1 * c->pitch, n = (size_t)(c->nxl - c->upd_x1) * c->pitch * sizeof(float);
         HIP_TRY(hipMemcpyAsync(d_out1 + off, d_pp + off, n, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(d_out2 + off, d_p + off, n, hipMemcpyDeviceToDevice, s));
+        if (mode == FDW_MODE_PLAIN_ALL) {      // the levels in between alternate the same way: level 0 carries pp's rows, level 1 p's
+            HIP_TRY(hipMemcpyAsync(bk->lvl0 + off, d_pp + off, n, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(bk->lvl1 + off, d_p + off, n, hipMemcpyDeviceToDevice, s));
+        }
     }
     return FDW_OK;
 }
@@ -929,7 +962,33 @@ static int back_loop(fdw_ctx* c, float* const src[4], float* const rcv[4], int g
     int rc;
     int it = 0;
     const bool pairs = two_step_pays(c);
+    // Four iterations per pair of passes through the wave pipeline where it pays: pass 1 reconstructs F_it .. F_{it+3} (all four levels are
+    // kept: the imaging condition needs each of them), pass 2 advances the receiver field four times, injects each iteration's samples and
+    // adds the four products F_{it+j} r^{it+j+1} to the image in iteration order.  Not where receiver rows lie beyond the time-stepped rows.
+    const bool pipe = pipe_pays(c) && c->prm.dialect == FDW_DIALECT_RTM && c->nbatch <= 1 && c->prm.nxb + c->nx <= c->upd_x1 && !c->no_back_pipe;
+    if (pipe && nsteps >= 2 + kPipeSteps) {
+        if ((rc = alloc_zero(&c->fld[8], field_elems(c))) || (rc = alloc_zero(&c->fld[9], field_elems(c)))) return rc;
+    }
     while (it < nsteps) {
+        if (pipe && it >= 2 && nsteps - it >= kPipeSteps) {
+            int o1 = -1, o2 = -1, q1 = -1, q2 = -1;
+            for (int i = 0; i < 4; i++) {
+                if (i != f1 && i != f0) { (o1 < 0 ? o1 : o2) = i; }
+                if (i != rn && i != ro) { (q1 < 0 ? q1 : q2) = i; }
+            }
+            StepnBack fb;
+            fb.lvl0 = c->fld[8]; fb.lvl1 = c->fld[9];
+            if ((rc = stepn_impl(c, FDW_MODE_PLAIN_ALL, src[f1], src[f0], c->d_v2, src[o1], src[o2], 0, nullptr, -1, 0, c->stream, RowRanges{}, nullptr, 0, &fb))) return rc;
+            StepnBack rb;
+            rb.plev[0] = c->fld[8]; rb.plev[1] = c->fld[9]; rb.plev[2] = src[o1]; rb.plev[3] = src[o2];
+            rb.img = c->d_img;
+            rb.inj_stride = -(int)nxs;                       // iteration it+1 reads the sample row before (time-reversed traces, R:328)
+            if ((rc = stepn_impl(c, FDW_MODE_RECV, rcv[rn], rcv[ro], c->d_v2, rcv[q1], rcv[q2], it > 0, samples(it), -1, gz, c->stream, RowRanges{}, nullptr, 0, &rb))) return rc;
+            f0 = o1; f1 = o2;
+            ro = q1; rn = q2;
+            it += kPipeSteps;
+            continue;
+        }
         if (pairs && nsteps - it >= 2) {
             const float *Fa, *Fb;   // source fields of iterations it, it+1
             if (it == 0) {

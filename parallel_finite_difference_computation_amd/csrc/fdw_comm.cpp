@@ -121,6 +121,7 @@ struct LocalGroup {
 
 struct fdw_comm {
     int rank = 0, world = 1, device = 0;
+    bool stub = false;                          // fdw_comm_init_stub: nothing travels (timing experiments)
     ncclComm_t nccl = nullptr;                  // RCCL backend
     std::shared_ptr<LocalGroup> grp;            // local backend
 };
@@ -159,6 +160,16 @@ extern "C" int fdw_comm_init_rank(const char id[FDW_COMM_ID_BYTES], int rank, in
         delete c;
         return fdw_fail(FDW_ECOMM, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, device, r->GetErrorString(rc));
     }
+    *out = c;
+    return FDW_OK;
+}
+
+extern "C" int fdw_comm_init_stub(int rank, int world, int device, fdw_comm** out)
+{
+    if (!out || world < 1 || rank < 0 || rank >= world) return fdw_fail(FDW_EINVAL, "comm_init_stub: rank %d of %d", rank, world);
+    fdw_comm* c = new (std::nothrow) fdw_comm();
+    if (!c) return fdw_fail(FDW_ENOMEM, "out of host memory");
+    c->rank = rank; c->world = world; c->device = device; c->stub = true;
     *out = c;
     return FDW_OK;
 }
@@ -216,7 +227,7 @@ extern "C" void fdw_comm_destroy(fdw_comm* c)
 int fdw_comm_exchange(fdw_comm* c, int nfields, float* const* fields, size_t send_lo, size_t recv_lo, size_t send_hi, size_t recv_hi,
                       size_t count, hipStream_t stream)
 {
-    if (!c || c->world == 1 || count == 0 || nfields == 0) return FDW_OK;
+    if (!c || c->world == 1 || c->stub || count == 0 || nfields == 0) return FDW_OK;
     if (nfields > FDW_COMM_MAX_FIELDS) return fdw_fail(FDW_EINVAL, "exchange: %d fields", nfields);
     const bool has_lo = c->rank > 0, has_hi = c->rank < c->world - 1;
     if (c->nccl) {
@@ -291,7 +302,7 @@ int fdw_comm_exchange(fdw_comm* c, int nfields, float* const* fields, size_t sen
 extern "C" int fdw_comm_allreduce(fdw_comm* c, double* value, int op_max)
 {
     if (!c || !value) return fdw_fail(FDW_EINVAL, "allreduce: NULL argument");
-    if (c->world == 1) return FDW_OK;
+    if (c->world == 1 || c->stub) return FDW_OK;
     if (c->nccl) {
         // RCCL has no host values: bounce one float pair through the device (sum; max via the sign-split trick is not needed here)
         HIP_TRY(hipSetDevice(c->device));

@@ -149,6 +149,9 @@ __device__ __forceinline__ float laplacian_dd_pt(const float* W, int e, const fl
 // the update once prod = (v2*dt2)*lap is formed (fp32, as the reference's float expression does; R:89)
 __device__ __forceinline__ float leapfrog_prod(float p, float pp, float prod)
 {
+#if FDW_ABL_BITS & 512
+    return (2.0f * p - pp) + prod;      // timing experiment: what the fp64 chain (3 cvt + fma + add + cvt per cell) costs
+#endif
     // 2.*p - pp: the product is exact in double, so the fused form rounds once exactly like the reference's two operations
     const double d = __builtin_fma(2.0, (double)p, -(double)pp) + (double)prod;
     float r = (float)d;
@@ -240,6 +243,14 @@ template <int H, class Row>
 __device__ __forceinline__ void laplacian_quad(const ZPairs& z, Row&& row, const CoefPairs<H>& c, v2f& lap01, v2f& lap23)
 {
     v2f az0 = {0.0f, 0.0f}, ax0 = {0.0f, 0.0f}, az1 = {0.0f, 0.0f}, ax1 = {0.0f, 0.0f};
+#if FDW_ABL_BITS & 256
+    {      // timing experiment: every input kept alive, almost no arithmetic
+        const f4 r0 = row(std::integral_constant<int, 0>{}), r8 = row(std::integral_constant<int, 2 * H>{});
+        lap01 = z.E[0] + z.E[5] + v2f{r0.v[0], r0.v[1]} + v2f{r8.v[0], r8.v[1]};
+        lap23 = z.O[0] + z.O[4] + v2f{r0.v[2], r0.v[3]} + v2f{r8.v[2], r8.v[3]};
+        return;
+    }
+#endif
     static_for<2 * H + 1>([&](auto IO) {
         constexpr int io = decltype(IO)::value;
         constexpr int k0 = 4 - H + io, k1 = 6 - H + io;

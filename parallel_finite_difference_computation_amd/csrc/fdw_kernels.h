@@ -12,10 +12,12 @@ enum {
     FDW_MODE_MOD = 4,    // forward-modelling step of the CPU-serial sibling (mod_main: fd_step + ptsrc + taper_apply + trace sample)
     FDW_MODE_DD_FWD = 5, // its stored-wavefield RTM, source pass (rtm_main.cpp:165-184: fd_step + one-cell source + taper_apply2)
     FDW_MODE_BACK = 7,   // one whole backward iteration of fd_back in a single pass: source-field step + receiver step + imaging (R:317-329)
+    FDW_MODE_PLAIN_ALL = 8, // wave-pipeline kernel only: PLAIN with all four time levels stored (source field of the backward loop)
     FDW_MODE_DD_RECV = 6 // its receiver pass (rtm_main.cpp:197-220) + img += stored source field * CURRENT receiver field (rtm_main.cpp:224-230)
 };
 
 constexpr int kMaxFastHalfOrder = 4;   // register-window kernel is instantiated for order 2,4,6,8
+constexpr int kMaxPipeSteps = 4;       // time levels of one pass of the wave-pipeline kernel
 
 // Everything one launch needs, passed by value (lives in SGPRs / the scalar cache).
 // All row indices are LOCAL rows of this device's slab; the host translates global extents.
@@ -87,6 +89,15 @@ struct Step2Args {
     float gw[4][4];
     float* rec;            // [steps of the pass][rec_n]: wave k writes row k
     int rec_z, rec_x0, rec_n;
+    // pipeline kernel, backward loop (fd_back, R:302-339), two passes per kPipeSteps iterations:
+    //   FDW_MODE_PLAIN_ALL  the source field: like PLAIN, but EVERY wave stores its time level (wave 0 -> lvl0, wave 1 -> lvl1, then out1, out2),
+    //                       because the imaging condition of iteration it+k needs F_{it+k} at every point
+    //   FDW_MODE_RECV       the receiver field: wave k adds the trace samples of iteration it+k (inj + k * inj_stride) on column inj_z of rows
+    //                       [inj_x, inj_x+inj_n) and multiplies its new row with the same row of plev[k] = F_{it+k}; the four products are
+    //                       added to the image row in iteration order as it travels from wave to wave through an LDS FIFO
+    float *lvl0, *lvl1;
+    const float* plev[kMaxPipeSteps];
+    int inj_stride;
 };
 hipError_t launch_step2(const Step2Args& a, int half_order, int mode, hipStream_t s);
 

@@ -26,6 +26,9 @@ namespace fdw {
 #ifndef FDW_PIPE_PF
 #define FDW_PIPE_PF 2      // rows of global look-ahead of wave 0
 #endif
+#ifndef FDW_PIPE_OPT
+#define FDW_PIPE_OPT 1     // 1: waves skip the march steps outside their useful window; 4: the frame masks only in workgroups that touch the frame
+#endif                     //    (measured slower: 581 vs 590 Gpoints/s at 8192^2)
 #ifndef FDW_PIPE_ROWS
 #define FDW_PIPE_ROWS 1    // march steps between two workgroup barriers of the pipeline kernel (1 or 2)
 #endif
@@ -38,9 +41,11 @@ __device__ __forceinline__ int pipe_fifo_slot(int m)
     else return ((m % FD) + FD) % FD;
 }
 
-template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int ROWS = FDW_PIPE_ROWS>
+// BK: 0 forward / modelling loops; 1 source field of the backward loop (every wave stores its level); 2 receiver field of the backward
+// loop (INJ = 2: trace samples per level, imaging against plev[k], image rows chained through imf)
+template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0, int ROWS = FDW_PIPE_ROWS>
 __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const int k, const int cs, const int xa, const int xe,
-                                       f4 (*link)[2][2][ROWS][64], f4 (*fifo)[64])
+                                       f4 (*link)[2][2][ROWS][64], f4 (*fifo)[64], f4 (*imf)[64] = nullptr)
 {
     // ROWS march steps between two workgroup barriers (1 or 2): a wave consumes what its predecessor produced during the previous
     // ROWS steps, so consecutive waves work H + ROWS rows apart and a wave's first good row comes ROWS later per stage.
@@ -54,20 +59,25 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
     const int z0 = cell * 4;
     const unsigned voff = (unsigned)min(max(z0, 0), a.pitch - 4) * 4u;
     const bool own = (lane >= NS) && (lane <= 63 - NS) && (z0 >= 0) && (z0 < a.pitch);
-    const unsigned soff = (own && k >= NS - 2) ? voff : kLaneOff;         // only the last two waves store
+    const unsigned soff = (own && (BK == 1 || k >= NS - 2)) ? voff : kLaneOff;      // only the last two waves store (BK 1: all four levels are kept)
     const unsigned loff = first ? voff : kLaneOff;                        // only wave 0 loads
     const unsigned row_bytes = (unsigned)a.pitch * 4u;
     const int rowmax = a.nxl - 1;
     const unsigned arr_bytes = (unsigned)a.nxl * row_bytes;               // < 2 GiB (checked by the host)
     const __amdgpu_buffer_rsrc_t rs_p = array_rsrc(a.p, arr_bytes), rs_pp = array_rsrc(a.pp, arr_bytes), rs_v2 = array_rsrc(a.v2, arr_bytes);
-    const __amdgpu_buffer_rsrc_t rs_out = array_rsrc((k == NS - 1) ? a.out2 : a.out1, arr_bytes);
+    const __amdgpu_buffer_rsrc_t rs_out = array_rsrc((k == NS - 1) ? a.out2 : ((BK == 1 && k < NS - 2) ? (k == 0 ? a.lvl0 : a.lvl1) : a.out1), arr_bytes);
+    // BK 2: this wave's source-field level and, for wave 0 / the last wave, the image
+    const __amdgpu_buffer_rsrc_t rs_lev = array_rsrc(BK == 2 ? a.plev[k] : a.p, arr_bytes), rs_img = array_rsrc(BK == 2 ? a.img : a.out1, arr_bytes);
+    const unsigned ioff = (BK == 2 && own) ? voff : kLaneOff;             // imaging: owned lanes only
 
     const bool wave_tap = TAPER && (cs * 4 < a.ztap);
     const bool xtap = wave_tap && ((xa - NS * H < a.xt_lo) || (xe + NS * H > a.xt_hi));
     const CoefPairs<H> cpk = coef_pairs<H>(a.cx, a.cz);
     const int blob = (INJ == 3) ? 3 : 0;                                  // INJ 3: 7x7 Gaussian source of the CPU-serial sibling (ptsrc.c:49-55)
-    const bool inj_here = (INJ != 0) && (a.inj_z + blob >= cs * 4) && (a.inj_z - blob < cs * 4 + 256) && (a.inj_x + blob >= xa - NS * H) && (a.inj_x - blob < xe + NS * H);
-    const float injv = inj_here ? sload(a.inj, k) : 0.0f;                 // source sample of this wave's time step (R:119-122)
+    const bool inj_here = (INJ == 2) ? ((a.inj_z >= cs * 4) && (a.inj_z < cs * 4 + 256) && (a.inj_x < xe + NS * H) && (a.inj_x + a.inj_n > xa - NS * H))
+                                     : ((INJ != 0) && (a.inj_z + blob >= cs * 4) && (a.inj_z - blob < cs * 4 + 256) && (a.inj_x + blob >= xa - NS * H) && (a.inj_x - blob < xe + NS * H));
+    const float injv = (INJ != 2 && inj_here) ? sload(a.inj, k) : 0.0f;    // source sample of this wave's time step (R:119-122)
+    const float* injk = a.inj + (INJ == 2 ? k * a.inj_stride : 0);        // INJ 2: the trace samples of iteration it + k (R:124-131)
     const bool rec_here = DD && (a.rec != nullptr) && (a.rec_z >= cs * 4) && (a.rec_z < cs * 4 + 256);
 
     bool mlap[4], mupd[4], znc[4], ihit[4];
@@ -109,6 +119,11 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
     const int kp = max(k - 1, 0);
     f4 ring[R];
     f4 qpp[PF], qv2[PF];
+    f4 qlv[BK == 2 ? PF : 1], qim[BK == 2 ? PF : 1];                    // BK 2: this wave's source-field rows and (wave 0) the image rows, PF steps ahead
+    const unsigned imoff = (BK == 2 && first) ? ioff : kLaneOff;          // only wave 0 reads the image
+    bool zim[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) zim[e] = (z0 + e >= 0) && (z0 + e < a.img_z1);
     constexpr int NV = LOOK > PF ? LOOK : PF;
     static_for<2 * H>([&](auto K) {
         constexpr int kk = decltype(K)::value;
@@ -122,6 +137,10 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             constexpr int mm = j + PF;
             qpp[mm] = load_pw(rs_pp, s0 + mm);
             qv2[mm] = load_pw(rs_v2, s0 + mm);
+            if constexpr (BK == 2) {
+                qlv[mm] = f4_load_arr(rs_lev, ioff, rowoff(rk + mm), (FDW_NT & 1) != 0);
+                qim[mm] = f4_load_arr(rs_img, imoff, rowoff(rk + mm), (FDW_NT & 1) != 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -132,6 +151,17 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         });
     }
 
+    // A wave has nothing useful to compute before its window holds good rows of its predecessor (march steps < k (2H + ROWS); during the
+    // last 2H of them it only collects the rows entering its window) nor after the last row a later level needs from it: outside
+    // [m_lo, m_hi) it keeps the barriers and its memory instructions, which are predicated off through the buffer descriptor so that
+    // the s_waitcnt counting stays exact.  That frees a fifth of the issue slots of a 43-row chunk (7 % at 173 rows) for the other
+    // workgroups of the CU.
+    const int m_lo = k * (2 * H + ROWS), m_hi = (xe - xa) + 2 * (NS - 1) * H + k * ROWS;
+    // The frame of the grid (rows / columns where the Laplacian or the update is masked) only concerns the workgroups that touch it;
+    // all others take the wave-uniform branch around the mask selects.
+    const bool edge = !(FDW_PIPE_OPT & 4) || (cs * 4 < a.lap_z0) || (cs * 4 + 256 > min(a.lap_z1, a.upd_z1)) || (xa - (NS - 1) * H - NS * SK < max(a.lap_x0, 0)) ||
+                      (xe + (NS - 1) * H + NS * SK > min(a.lap_x1, a.upd_x1));
+
     auto row_step = [&](const int mb, auto UU) {
         constexpr int U = decltype(UU)::value;
         constexpr int Q = U % PF;
@@ -140,26 +170,35 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         const int r = rk + m;
         constexpr int SLOT = U % ROWS;                          // which of the ROWS rows between two barriers
         const int par = (m / ROWS) & 1;                          // link buffers alternate per barrier interval
-        // ---- what the previous wave handed over during march step m-1 ----
-#if FDW_ABL_BITS & 128
-        const f4 nr = ring[U], ppl = ring[(U + 1) % R], v2l = ring[(U + 2) % R];
-#else
-        const f4 nr = link[kp][par ^ 1][0][SLOT][lane];
-        const f4 ppl = link[kp][par ^ 1][1][SLOT][lane];
-        const f4 v2l = fifo[pipe_fifo_slot<FD>(m - k * SK)][lane];
-#endif
-        f4 ppt, v2t;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            ring[E].v[e] = first ? ring[E].v[e] : nr.v[e];
-            ppt.v[e] = first ? qpp[Q].v[e] : ppl.v[e];
-            v2t.v[e] = first ? qv2[Q].v[e] : v2l.v[e];
-        }
+        const bool act = !(FDW_PIPE_OPT & 1) || ((m >= m_lo) && (m < m_hi));
+        const bool fill = !(FDW_PIPE_OPT & 1) || ((m >= m_lo - 2 * H) && (m < m_hi));     // collecting the rows that enter the window
+        // ---- what the previous wave handed over during march step m-1: the row entering this wave's window ----
+        if (fill) {
 #if !(FDW_ABL_BITS & 128)
-        if (first) fifo[pipe_fifo_slot<FD>(m)][lane] = qv2[Q];
+            if (!first) ring[E] = link[kp][par ^ 1][0][SLOT][lane];
 #endif
+            if (wave_tap) taper_row(ring[E], r + H);            // damped once as "p" of this step
+        }
+        f4 u;
+        float im0, im1, im2, im3;                               // the image row (BK 2), as scalars: defined on every path without an instruction
+        if constexpr (BK == 2) asm volatile("" : "=v"(im0), "=v"(im1), "=v"(im2), "=v"(im3));
+        if (act) {
+        f4 ppt, v2t;
+        if (first) {                                            // wave 0: its rows come from global memory (loaded PF steps ago)
+            ppt = qpp[Q];
+            v2t = qv2[Q];
+#if !(FDW_ABL_BITS & 128)
+            fifo[pipe_fifo_slot<FD>(m)][lane] = qv2[Q];
+#endif
+        } else {
+#if FDW_ABL_BITS & 128
+            ppt = ring[(U + 1) % R]; v2t = ring[(U + 2) % R];
+#else
+            ppt = link[kp][par ^ 1][1][SLOT][lane];
+            v2t = fifo[pipe_fifo_slot<FD>(m - k * SK)][lane];
+#endif
+        }
         if (wave_tap) {
-            taper_row(ring[E], r + H);                          // entering row: damped once as "p" of this step
             taper_row(ppt, r);                                  // "pp": from memory once (+ once owed), from LDS once more
             if (first && a.pp_twice) taper_row(ppt, r);
         }
@@ -176,7 +215,6 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         }
         const bool rowok = (r >= a.lap_x0) && (r < a.lap_x1);
         const bool rowupd = (r >= 0) && (r < a.upd_x1);
-        f4 u;
         if constexpr (DD) {
             // this wave's p field is P of iteration it0 + k: its trace sample (mod_main.cpp:155-157); owned lanes and rows only
             if (rec_here && own && r >= xa && r < xe && r >= a.rec_x0 && r < a.rec_x0 + a.rec_n) {
@@ -203,13 +241,14 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             laplacian_quad<H>(zp, [&](auto IO) -> const f4& { return ring[(U + decltype(IO)::value) % R]; }, cpk, lapq[0], lapq[1]);
             static_for<2>([&](auto PP) {
                 constexpr int P = decltype(PP)::value;
-                const v2f lap2 = lapq[P];
-                const v2f prod2 = (f4_pair(v2t, P) * a.dt2) * v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
+                v2f lap2 = lapq[P];
+                if (edge) lap2 = v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
+                const v2f prod2 = (f4_pair(v2t, P) * a.dt2) * lap2;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int e = 2 * P + q;
                     const float upd = leapfrog_prod(c1.v[e], ppt.v[e], q ? prod2.y : prod2.x);
-                    u.v[e] = (rowupd && mupd[e]) ? upd : ppt.v[e];
+                    u.v[e] = (!edge || (rowupd && mupd[e])) ? upd : ppt.v[e];
                 }
             });
         }
@@ -218,6 +257,26 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
 #pragma unroll
                 for (int e = 0; e < 4; ++e) u.v[e] = ihit[e] ? u.v[e] + injv : u.v[e];
             }
+        }
+        if constexpr (INJ == 2) {
+            if (inj_here && r >= a.inj_x && r < a.inj_x + a.inj_n) {      // kernel_sism: one add per receiver row (R:124-131)
+                const float v = sload(injk, r - a.inj_x);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u.v[e] = ihit[e] ? u.v[e] + v : u.v[e];
+            }
+        }
+        if constexpr (BK == 2) {
+            // kernel_img (R:133-144) for iteration it + k: img += F_{it+k} * (the receiver field just formed).  The image row enters at wave 0
+            // from memory, collects the four products in iteration order on its way through the LDS FIFO and leaves from the last wave.
+            f4 im;
+            if (first) im = qim[Q];
+            else im = imf[r & 15][lane];
+            if (r >= xa && r < xe) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) im.v[e] = zim[e] ? im.v[e] + qlv[Q].v[e] * u.v[e] : im.v[e];
+            }
+            if (k < NS - 1) imf[r & 15][lane] = im;
+            im0 = im.v[0]; im1 = im.v[1]; im2 = im.v[2]; im3 = im.v[3];
         }
         if constexpr (INJ == 3) {
             if (inj_here && r >= a.inj_x - 3 && r <= a.inj_x + 3) {
@@ -236,15 +295,29 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         link[k][par][0][SLOT][lane] = u;
         link[k][par][1][SLOT][lane] = ring[U];
 #endif
-        const unsigned so = ((r >= xa) && (r < xe) && (m < M)) ? soff : kLaneOff;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("" : "=v"(u.v[e]));      // defined (no instruction) on the path that skips the row
+        }
+        const unsigned so = (act && (r >= xa) && (r < xe) && (m < M)) ? soff : kLaneOff;
 #if FDW_ABL_BITS & 1024
         ring[U] = u;
 #else
         f4_store_arr(rs_out, so, rowoff(r), u);
+        if constexpr (BK == 2) {
+            const unsigned sim = (k == NS - 1 && act && (r >= xa) && (r < xe)) ? ioff : kLaneOff;
+            f4 im;
+            im.v[0] = im0; im.v[1] = im1; im.v[2] = im2; im.v[3] = im3;
+            f4_store_arr(rs_img, sim, rowoff(r), im);
+        }
         // ---- look-ahead loads of wave 0 into the slots this step freed ----
         ring[U] = load_p(b0 + m + R);
         qpp[Q] = load_pw(rs_pp, s0 + m + PF);
         qv2[Q] = load_pw(rs_v2, s0 + m + PF);
+        if constexpr (BK == 2) {
+            qlv[Q] = f4_load_arr(rs_lev, ioff, rowoff(r + PF), (FDW_NT & 1) != 0);
+            qim[Q] = f4_load_arr(rs_img, imoff, rowoff(r + PF), (FDW_NT & 1) != 0);
+        }
 #endif
 #if !(FDW_ABL_BITS & 64)
         if constexpr (SLOT == ROWS - 1) __syncthreads();
@@ -255,8 +328,8 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         static_for<R>([&](auto UU) { row_step(mb, UU); });
 }
 
-template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false>
-__global__ __launch_bounds__(64 * NS, FDW_PIPE_ROWS != 1 ? 3 : (DD ? 4 : 5)) void fdw_stepn_kernel(const Step2Args a)
+template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0>
+__global__ __launch_bounds__(64 * NS, (FDW_PIPE_ROWS != 1 || BK == 2) ? 3 : (DD ? 4 : 5)) void fdw_stepn_kernel(const Step2Args a)
 {
     const int lane = threadIdx.x & 63;
     const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -271,7 +344,13 @@ __global__ __launch_bounds__(64 * NS, FDW_PIPE_ROWS != 1 ? 3 : (DD ? 4 : 5)) voi
     if (xa >= xe) return;
     __shared__ f4 link[NS][2][2][FDW_PIPE_ROWS][64];       // [producer wave][parity][0 new row | 1 row leaving the window][row of the interval][lane]
     __shared__ f4 fifo[pipe_fifo_rows(NS, H, FDW_PIPE_ROWS)][64];
-    marchn<H, NS, TAPER, INJ, PF, DD>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo);
+    if constexpr (BK == 2) {
+        static_assert(FDW_PIPE_ROWS == 1, "the image FIFO assumes one row per barrier");
+        __shared__ f4 imf[16][64];                         // image rows on their way from wave to wave (a row is 3 (H + 1) = 15 steps under way)
+        marchn<H, NS, TAPER, INJ, PF, DD, BK>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo, imf);
+    } else {
+        marchn<H, NS, TAPER, INJ, PF, DD, BK>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo);
+    }
 }
 
 hipError_t launch_stepn(const Step2Args& a, int h, int mode, hipStream_t s)
@@ -283,6 +362,8 @@ hipError_t launch_stepn(const Step2Args& a, int h, int mode, hipStream_t s)
     case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 1, FDW_PIPE_PF>), grid, block, 0, s, a); break;
     case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, false, 0, FDW_PIPE_PF>), grid, block, 0, s, a); break;
     case FDW_MODE_MOD:   hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 3, FDW_PIPE_PF, true>), grid, block, 0, s, a); break;
+    case FDW_MODE_PLAIN_ALL: hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, false, 0, FDW_PIPE_PF, false, 1>), grid, block, 0, s, a); break;
+    case FDW_MODE_RECV:  hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 2, FDW_PIPE_PF, false, 2>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

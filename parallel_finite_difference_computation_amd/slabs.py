@@ -39,6 +39,13 @@ class Comm:
         check(lib().fdw_comm_init_local(world, dev, arr))
         return [cls(C.c_void_p(arr[r])) for r in range(world)]
 
+    @classmethod
+    def stub(cls, rank, world, device=0):
+        """Rank `rank` of a world whose other ranks do not exist: nothing travels.  Timing experiments only."""
+        h = C.c_void_p()
+        check(lib().fdw_comm_init_stub(rank, world, device, C.byref(h)))
+        return cls(h)
+
     rank = property(lambda self: lib().fdw_comm_rank(self._h))
     world = property(lambda self: lib().fdw_comm_world(self._h))
     device = property(lambda self: lib().fdw_comm_device(self._h))

@@ -341,6 +341,42 @@ def test_multi_process_bench_rehearsal_on_one_gpu(ranks, opts, tmp_path):
     assert out["n_gpus"] == ranks and out["scaling"] == "strong" and out["result_finite_nonzero"] and out["value"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_multi_gpu_code_path_on_one_rank(tmp_path):
+    """bench.py's --backend nccl path (communicator over librccl, fdw_slabs_dev_forward: the code the 8-GPU run executes) forced onto one
+    rank: the JSON line must come out and agree with the plain single-GPU path on the field it ends with (finite, non-zero)."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "1024", "--steps", "24", "--warmup", "6", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=tmp_path, env=dict(os.environ, FDW_FORCE_SLAB_DRIVER="c"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["result_finite_nonzero"] and out["value"] > 0 and out["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,opts", [(1, []), (2, ["--backend", "gloo", "--ksteps", "4"]), (3, ["--backend", "gloo", "--ksteps", "3", "--steps", "11"])],
+                         ids=["1rank-c-driver", "2ranks-gloo-k4", "3ranks-gloo-k3-leftover"])
+def test_bench_rtm_slab_workload(ranks, opts, tmp_path):
+    """bench.py --workload rtm-slab: forward + backward + imaging of one shot under the slab decomposition.  One rank: the C driver
+    (fdw_slabs_*) on the whole grid; 2 and 3 ranks: real processes sharing this GPU over gloo through the Python harness
+    (decomp.SlabForward + SlabBack), with the gathered image compared bitwise with a single-domain run of the same shots."""
+    import json
+    import sys
+    base = [os.path.join(ROOT, "bench.py"), "--workload", "rtm-slab", "--gpus", str(ranks), "--size", "1024", "--steps", "12", "--warmup", "4", "--no-cpu-baseline"] + opts
+    if ranks == 1:
+        cmd = [sys.executable] + base
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + base
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-3000:]
+    if ranks > 1:
+        assert f"decomposed image ({ranks} slabs) == single domain, bitwise: True" in r.stderr
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == ranks and out["result_finite_nonzero"] and out["value"] > 0 and out["roofline"]["frac"] <= 1.0
+
+
 def _free_port():
     import socket
     s = socket.socket()
