@@ -365,8 +365,10 @@ def run_rtm_slab_workload(args):
             g = SlabGeometry(geom_rank, geom_world, n, ORDER // 2, k if geom_world > 1 else 1)
             ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank, slab=(g.x_off, g.nxl) if geom_world > 1 else None)
             sl, pitch, nbuf = None, ctx.pitch, 2
-        st = dict(sl=sl, ctx=ctx, g=g, pitch=pitch)
-        st["fld"] = [torch.zeros((g.nxl, pitch), device=dev) for _ in range(nbuf + 2)]          # forward buffers + the receiver pair
+        nfb, nrb = sl.back_buffers() if c_driver else (2, 2)
+        nsrc = max(nbuf, nfb)                                                                  # forward buffers double as the backward loop's source-field buffers
+        st = dict(sl=sl, ctx=ctx, g=g, pitch=pitch, nsrc=nsrc)
+        st["fld"] = [torch.zeros((g.nxl, pitch), device=dev) for _ in range(nsrc + nrb)]       # ... + the receiver buffers
         gen = torch.Generator(device=dev)
         for f_, seed in ((st["fld"][0], 0x5EED0001), (st["fld"][1], 0x5EED0002)):
             gen.manual_seed(seed)
@@ -381,7 +383,7 @@ def run_rtm_slab_workload(args):
 
     def shot(st, nsteps):
         """forward nsteps, snapshot hand-over, backward nsteps with imaging (enqueue; the caller synchronises)."""
-        fld, rcv = st["fld"], st["fld"][st["nbuf"]:]
+        fld, rcv = st["fld"], st["fld"][st["nsrc"]:]
         if c_driver:
             sl = st["sl"]
             st["ip"], st["ipp"] = sl.dev_forward([f_.data_ptr() for f_ in fld[:st["nbuf"]]], st["v2"].data_ptr(), srce.data_ptr(), sx, sz, 0, nsteps, True,
@@ -390,8 +392,8 @@ def run_rtm_slab_workload(args):
             with torch.cuda.stream(torch.cuda.ExternalStream(sl.stream)):
                 rcv[0].zero_()
                 rcv[1].zero_()                                                        # R:513-514
-            sl.dev_back([fld[st["ip"]].data_ptr(), fld[st["ipp"]].data_ptr()], [r_.data_ptr() for r_ in rcv], st["v2"].data_ptr(), samples.data_ptr(),
-                        gz, st["img"].data_ptr(), 0, nsteps)
+            sl.dev_back([f_.data_ptr() for f_ in fld[:st["nsrc"]]], [r_.data_ptr() for r_ in rcv], st["v2"].data_ptr(), samples.data_ptr(),
+                        gz, st["img"].data_ptr(), 0, nsteps, role=(st["ip"], st["ipp"], 0, 1))
         else:
             fw = st["fw"]
             fw.it = 0

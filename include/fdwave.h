@@ -150,6 +150,14 @@ int fdw_shot(fdw_ctx *ctx, const float *v2, int sx, int sz, int gz, const float 
  *                 d_img is [nxl][pitch] on the extended grid.  The caller swaps (d_f1, d_f0) when step_source and (d_pr, d_ppr) always.
  *                 Rows of different calls of one iteration must be disjoint; pp_twice as for fdw_dev_step.  One launch where the fused
  *                 backward kernel exists (order <= 8), two otherwise.
+ * fdw_dev_back4   FOUR iterations of that loop (no snapshot iterations among them) as two passes of the wave-pipeline kernel (order 8, fields
+ *                 < 2 GiB, no receiver rows beyond the time-stepped rows; fdw_back_pipe_active says whether fdw_back itself takes this path on this
+ *                 grid): pass 1 reconstructs F_it .. F_{it+3} from d_f1 = F_{it-1}, d_f0 = F_{it-2} into d_lvl0, d_lvl1, d_fo1, d_fo2; pass 2
+ *                 advances the receiver field four times (d_pr = r^it, d_ppr = r^{it-1} -> d_ro1 = r^{it+3}, d_ro2 = r^{it+4}), injecting
+ *                 d_samples + j * sample_stride at iteration it + j, and adds the four imaging products to d_img in iteration order.  Local
+ *                 rows [r0, r1) and [r0b, r1b) (r1 < 0: all); rows within 16 of a range end are read from the inputs, so a slab driver
+ *                 shrinks the range by 16 rows per call between two halo exchanges.  No buffer may alias another.  Bit-identical to four
+ *                 fdw_dev_back_iter calls.
  * fdw_dev_steps   nsteps FWD steps with internal role swapping; *d_srce is srce[] on the device
  *                 (may be NULL = no source).  After an odd number of steps the newest field is in
  *                 the buffer passed as d_pp, after an even number in d_p (as in the reference loop).
@@ -161,6 +169,10 @@ int fdw_dev_step(fdw_ctx *ctx, int mode, const float *d_p, float *d_pp, const fl
                  void *stream);
 int fdw_dev_back_iter(fdw_ctx *ctx, int step_source, const float *d_f1, float *d_f0, const float *d_pr, float *d_ppr, const float *d_v2,
                       int r0, int r1, int pp_twice, const float *d_samples, int gz, float *d_img, void *stream);
+int fdw_dev_back4(fdw_ctx *ctx, const float *d_f1, const float *d_f0, float *d_fo1, float *d_fo2, float *d_lvl0, float *d_lvl1, const float *d_pr,
+                  const float *d_ppr, float *d_ro1, float *d_ro2, const float *d_v2, const float *d_samples, int sample_stride, int gz, float *d_img,
+                  int pp_twice, int r0, int r1, int r0b, int r1b, int xchunk, void *stream);
+int fdw_back_pipe_active(const fdw_ctx *ctx);
 int fdw_dev_steps(fdw_ctx *ctx, float *d_p, float *d_pp, const float *d_v2, const float *d_srce, int sx, int sz,
                   int it0, int nsteps, int first_pp_twice, void *stream);
 int fdw_dev_steps_shrink(fdw_ctx *ctx, float *d_p, float *d_pp, const float *d_v2, const float *d_srce, int sx, int sz,
@@ -269,9 +281,11 @@ int fdw_rand_stream(fdw_ctx *ctx, unsigned long long draw_offset, long long n, i
  *                         are the reference's (d_p, d_pp) before its first swap on entry and after the loop on return.  Halo exchanges
  *                         included, overlapped with the interior rows; asynchronous (fdw_slabs_synchronize; fdw_slabs_stream is the
  *                         compute stream, for events).
- * fdw_slabs_dev_back      fd_back's loop (R:302-339): f[0], f[1] = (P, PP) of the forward pass on entry (P damped: fdw_dev_taper_finalize),
- *                         r[0], r[1] = the receiver pair (zero on entry), d_samples[nt][nx] with row it = d_obs[.][nt-1-it], d_img
- *                         [nxl][pitch] (owned rows meaningful).  *fswap / *rswap: roles inside the pairs exchanged (in: on entry, out: on return).
+ * fdw_slabs_dev_back      fd_back's loop (R:302-339) on caller-owned device arrays: f[role[0]], f[role[1]] = (F_{k-1}, F_{k-2}) -- before iteration 2
+ *                         the (P, PP) of the forward pass, P damped (fdw_dev_taper_finalize) --, r[role[2]], r[role[3]] = (r^k, r^{k-1}), zero
+ *                         before iteration 0; role[] is updated on return.  f holds nfb buffers and r nrb (fdw_slabs_back_buffers: 6 and 4
+ *                         where the slab runs four iterations per pair of pipeline passes, else 2 and 2).  d_samples[nt][nx] with row it =
+ *                         d_obs[.][nt-1-it], d_img [nxl][pitch] (owned rows meaningful).
  * fdw_slabs_shot          one shot of rtm_code's loop (R:496-520) on host arrays: every rank passes the GLOBAL v2[nxe][nze], srce[nt],
  *                         d_obs[nx][nt]; imloc[nx][nz] (global; accumulated into) and the optional P, PP [nxe][nze] receive this rank's
  *                         OWNED rows only.  Bit-identical to fdw_shot on the whole grid. */
@@ -298,8 +312,9 @@ void *fdw_slabs_stream(fdw_slabs *s);
 int fdw_slabs_synchronize(fdw_slabs *s);
 int fdw_slabs_dev_forward(fdw_slabs *s, float *const *buf, const float *d_v2, const float *d_srce, int sx, int sz, int it0, int nsteps,
                           int first_pp_twice, int *ip, int *ipp);
+int fdw_slabs_back_buffers(const fdw_slabs *s, int *nfb, int *nrb);
 int fdw_slabs_dev_back(fdw_slabs *s, float *const *f, float *const *r, const float *d_v2, const float *d_samples, int gz, float *d_img, int it0,
-                       int nsteps, int *fswap, int *rswap);
+                       int nsteps, int role[4]);
 int fdw_slabs_shot(fdw_slabs *s, const float *v2, int sx, int sz, int gz, const float *srce, const float *d_obs, float *imloc, float *P, float *PP);
 
 /* ---- tuning / introspection --------------------------------------------------------------------

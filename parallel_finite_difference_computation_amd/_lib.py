@@ -46,6 +46,8 @@ SIGNATURES = [
     ("fdw_field_bytes", C.c_size_t, [vp]),
     ("fdw_dev_step", C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),
     ("fdw_dev_back_iter", C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp]),
+    ("fdw_dev_back4", C.c_int, [vp] * 12 + [vp, C.c_int, C.c_int, vp] + [C.c_int] * 6 + [vp]),
+    ("fdw_back_pipe_active", C.c_int, [vp]),
     ("fdw_dev_steps", C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     ("fdw_dev_steps_shrink", C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 8 + [vp]),
     ("fdw_dev_step2", C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
@@ -89,7 +91,8 @@ SIGNATURES = [
     ("fdw_slabs_stream", vp, [vp]),
     ("fdw_slabs_synchronize", C.c_int, [vp]),
     ("fdw_slabs_dev_forward", C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    ("fdw_slabs_dev_back", C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), vp, vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("fdw_slabs_back_buffers", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("fdw_slabs_dev_back", C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), vp, vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     ("fdw_slabs_shot", C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, vp, vp]),
     ("fdw_set_tuning", C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("fdw_get_tables", C.c_int, [vp, vp, vp, vp, vp]),

@@ -714,6 +714,34 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
     return FDW_OK;
 }
 
+// FOUR iterations of fd_back's loop (R:317-329) as two passes of the wave-pipeline kernel on row ranges of the slab (see back_loop)
+extern "C" int fdw_dev_back4(fdw_ctx* c, const float* d_f1, const float* d_f0, float* d_fo1, float* d_fo2, float* d_lvl0, float* d_lvl1, const float* d_pr,
+                             const float* d_ppr, float* d_ro1, float* d_ro2, const float* d_v2, const float* d_samples, int sample_stride, int gz,
+                             float* d_img, int pp_twice, int r0, int r1, int r0b, int r1b, int xchunk, void* stream)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    if (c->prm.dialect != FDW_DIALECT_RTM || c->h != kMaxFastHalfOrder || (size_t)c->nxl * c->pitch * sizeof(float) >= (1ull << 31))
+        return fail(FDW_EINVAL, "back4: needs the RTM dialect, order 8 and fields below 2 GiB");
+    if (c->prm.nxb + c->nx > c->xlim) return fail(FDW_EINVAL, "back4: receiver rows beyond the time-stepped rows are not covered by the pipelined passes");
+    hipStream_t s = pick_stream(c, stream);
+    RowRanges rr;
+    rr.r0 = r0; rr.r1 = r1; rr.r0b = r0b; rr.r1b = r1b; rr.xchunk = xchunk;
+    StepnBack fb;
+    fb.lvl0 = d_lvl0; fb.lvl1 = d_lvl1;
+    int rc = stepn_impl(c, FDW_MODE_PLAIN_ALL, d_f1, d_f0, d_v2, d_fo1, d_fo2, 0, nullptr, -1, 0, s, rr, nullptr, 0, &fb);
+    if (rc) return rc;
+    StepnBack rb;
+    rb.plev[0] = d_lvl0; rb.plev[1] = d_lvl1; rb.plev[2] = d_fo1; rb.plev[3] = d_fo2;
+    rb.img = d_img;
+    rb.inj_stride = sample_stride;
+    return stepn_impl(c, FDW_MODE_RECV, d_pr, d_ppr, d_v2, d_ro1, d_ro2, pp_twice, d_samples, -1, gz, s, rr, nullptr, 0, &rb);
+}
+
+extern "C" int fdw_back_pipe_active(const fdw_ctx* c)
+{
+    return c && pipe_pays(c) && c->prm.dialect == FDW_DIALECT_RTM && c->prm.nxb + c->nx <= c->xlim && !c->no_back_pipe ? 1 : 0;
+}
+
 extern "C" int fdw_two_step_active(const fdw_ctx* c) { return c && two_step_pays(c) ? 1 : 0; }
 extern "C" int fdw_steps_per_pass(const fdw_ctx* c) { return !c ? 0 : (pipe_pays(c) ? kPipeSteps : (two_step_pays(c) ? 2 : 1)); }
 

@@ -64,12 +64,13 @@ struct fdw_slabs {
     int o0 = 0, o1 = 0, g_lo = 0, g_hi = 0, x_off = 0, nxl = 0, pitch = 0;
     bool has_lo = false, has_hi = false, overlap = true, pipe = false, stub = false;
     int nbuf = 2;                         // field buffers fdw_slabs_dev_forward rotates over
+    bool back_pipe = false;               // the backward loop goes four iterations per pair of pipeline passes
     hipStream_t compute = nullptr, commS = nullptr, side = nullptr;
     hipEvent_t ev = nullptr;
     hipStream_t send_after = nullptr;     // stream whose queued work the next exchange has to wait for (default: compute)
     bool fresh = false;                   // ghosts of the travelling fields are up to date
     // work arrays of the host-array entry points
-    float* fld[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* fld[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float *d_v2 = nullptr, *d_img = nullptr, *d_srce = nullptr, *d_samples = nullptr;
     size_t srce_cap = 0, samples_cap = 0;
 
@@ -171,6 +172,14 @@ extern "C" int fdw_slabs_create(const fdw_params* prm, fdw_comm* comm, int devic
     }
     s->pipe = no_pipe == 0.0;
     s->nbuf = (s->pipe || (s->world == 1 && fdw_steps_per_pass(s->ctx) > 1)) ? 4 : 2;
+    // the same question for the backward loop (one more condition: no receiver rows beyond the time-stepped rows); world 1: whatever the grid asks for
+    double no_bpipe = ((s->world == 1 ? fdw_steps_per_pass(s->ctx) == kPipe : s->pipe) && fdw_back_pipe_active(s->ctx)) ? 0.0 : 1.0;
+    if (const char* ev = getenv("FDW_SLAB_PIPE")) no_bpipe = (atoi(ev) && s->h == 4 && (s->world == 1 || s->ksteps % kPipe == 0) && s->prm.nxb + (s->prm.nxe - 2 * s->prm.nxb) <= (s->prm.compat ? 8 * (s->prm.nxe / 8) : s->prm.nxe)) ? 0.0 : 1.0;
+    if (comm && (rc = fdw_comm_allreduce(comm, &no_bpipe, 1)) != FDW_OK) {
+        fdw_slabs_destroy(s);
+        return rc;
+    }
+    s->back_pipe = no_bpipe == 0.0;
     *out = s;
     return FDW_OK;
 }
@@ -185,7 +194,7 @@ extern "C" void fdw_slabs_destroy(fdw_slabs* s)
             (void)hipStreamDestroy(st);
         }
     if (s->ev) (void)hipEventDestroy(s->ev);
-    for (float* f : {s->fld[0], s->fld[1], s->fld[2], s->fld[3], s->fld[4], s->fld[5], s->d_v2, s->d_img, s->d_srce, s->d_samples})
+    for (float* f : {s->fld[0], s->fld[1], s->fld[2], s->fld[3], s->fld[4], s->fld[5], s->fld[6], s->fld[7], s->fld[8], s->fld[9], s->d_v2, s->d_img, s->d_srce, s->d_samples})
         if (f) (void)hipFree(f);
     if (s->ctx) fdw_destroy(s->ctx);
     delete s;
@@ -302,59 +311,104 @@ extern "C" int fdw_slabs_dev_forward(fdw_slabs* s, float* const* buf, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
-// fd_back's loop (R:302-339) on the slab: f[0], f[1] = the source-field pair (F_{k-1}, F_{k-2}) -- before iteration 2 the forward pass's
-// P and PP --, r[0], r[1] = the receiver pair (r^k, r^{k-1}), d_samples [nt][nx] with row it = d_obs[.][nt-1-it], d_img [nxl][pitch].
-// Iterations it0 .. it0+nsteps-1; on return *fswap / *rswap say whether the roles inside the pairs are exchanged.
+// fd_back's loop (R:302-339) on the slab.  f[role[0]], f[role[1]] = the source-field pair (F_{k-1}, F_{k-2}) -- before iteration 2 the forward
+// pass's P and PP --, r[role[2]], r[role[3]] = the receiver pair (r^k, r^{k-1}); d_samples [nt][nx] with row it = d_obs[.][nt-1-it]; d_img
+// [nxl][pitch].  Where the slab runs the wave pipeline, four iterations go through one pair of passes (fdw_dev_back4) over f[0..3] (rotating)
+// + f[4], f[5] (the two levels in between) and r[0..3]; otherwise one fused launch per iteration on f[0..1], r[0..1].
 // ------------------------------------------------------------------------------------------------
-extern "C" int fdw_slabs_dev_back(fdw_slabs* s, float* const* f, float* const* r, const float* d_v2, const float* d_samples, int gz, float* d_img,
-                                  int it0, int nsteps, int* fswap, int* rswap)
+extern "C" int fdw_slabs_back_buffers(const fdw_slabs* s, int* nfb, int* nrb)
 {
-    if (!s || !f || !r || !d_v2 || !d_samples || !d_img) return fdw_fail(FDW_EINVAL, "slabs back: NULL argument");
+    if (!s) return fdw_fail(FDW_EINVAL, "slabs is NULL");
+    if (nfb) *nfb = s->back_pipe ? 6 : 2;
+    if (nrb) *nrb = s->back_pipe ? 4 : 2;
+    return FDW_OK;
+}
+
+extern "C" int fdw_slabs_dev_back(fdw_slabs* s, float* const* f, float* const* r, const float* d_v2, const float* d_samples, int gz, float* d_img,
+                                  int it0, int nsteps, int role[4])
+{
+    if (!s || !f || !r || !d_v2 || !d_samples || !d_img || !role) return fdw_fail(FDW_EINVAL, "slabs back: NULL argument");
+    for (int i = 0; i < 4; i++)      // without the pipeline only the four named buffers are touched (they may sit anywhere among four)
+        if (role[i] < 0 || role[i] >= 4) return fdw_fail(FDW_EINVAL, "slabs back: role[%d] = %d outside the rotating buffers", i, role[i]);
+    if (role[0] == role[1] || role[2] == role[3]) return fdw_fail(FDW_EINVAL, "slabs back: a pair names one buffer twice");
     HIP_TRY(hipSetDevice(s->device));
     fdw_ctx* c = s->ctx;
     const int h = s->h, G = s->G, nxl = s->nxl;
     const size_t nx = (size_t)(s->prm.nxe - 2 * s->prm.nxb);
-    float *f1 = f[fswap && *fswap ? 1 : 0], *f0 = f[fswap && *fswap ? 0 : 1];
-    float *rn = r[rswap && *rswap ? 1 : 0], *ro = r[rswap && *rswap ? 0 : 1];
+    int f1 = role[0], f0 = role[1], rn = role[2], ro = role[3];
     int it = it0, done = 0;
+    // one iteration on rows [a, b)
     auto iter = [&](int a, int b) {
         if (a >= b) return (int)FDW_OK;
         const float* smp = d_samples + (size_t)it * nx;
         if (it < 2) {      // the source field is a snapshot as it stands: iteration 0 images u^nt (PP), iteration 1 u^{nt-1} (P)
-            const float* F = it == 0 ? f0 : f1;
-            return fdw_dev_back_iter(c, 0, F, nullptr, rn, ro, d_v2, a, b, it > 0, smp, gz, d_img, s->compute);
+            const float* F = it == 0 ? f[f0] : f[f1];
+            return fdw_dev_back_iter(c, 0, F, nullptr, r[rn], r[ro], d_v2, a, b, it > 0, smp, gz, d_img, s->compute);
         }
-        return fdw_dev_back_iter(c, 1, f1, f0, rn, ro, d_v2, a, b, 1, smp, gz, d_img, s->compute);
+        return fdw_dev_back_iter(c, 1, f[f1], f[f0], r[rn], r[ro], d_v2, a, b, 1, smp, gz, d_img, s->compute);
     };
-    auto advance = [&] {
-        if (it >= 2) std::swap(f1, f0);      // F_k was written over F_{k-2}
-        std::swap(rn, ro);                   // R:331-333
-        it++;
+    // four iterations on rows [a, b) (+ [a2, b2)): F_it .. F_{it+3} into f[4], f[5], f[o1], f[o2]; r^{it+3}, r^{it+4} into r[q1], r[q2]
+    int o1 = 0, o2 = 0, q1 = 0, q2 = 0;
+    auto pick_spares = [&] {
+        o1 = o2 = q1 = q2 = -1;
+        for (int i = 0; i < 4; i++) {
+            if (i != f1 && i != f0) { (o1 < 0 ? o1 : o2) = i; }
+            if (i != rn && i != ro) { (q1 < 0 ? q1 : q2) = i; }
+        }
     };
+    auto pass = [&](int a, int b, int a2, int b2, int xchunk) {
+        if (a >= b && a2 >= b2) return (int)FDW_OK;
+        return fdw_dev_back4(c, f[f1], f[f0], f[o1], f[o2], f[4], f[5], r[rn], r[ro], r[q1], r[q2], d_v2, d_samples + (size_t)it * nx, (int)nx, gz, d_img,
+                             it > 0, a, b, a2, b2, xchunk, s->compute);
+    };
+    const int cycle = s->world > 1 ? s->ksteps : (1 << 30);
     while (done < nsteps) {
-        const int kk = std::min(s->ksteps, nsteps - done);
+        const int kk = std::min(cycle, nsteps - done);
         const bool more = done + kk < nsteps;
-        float* four[4] = {f1, f0, rn, ro};
+        float* four[4] = {f[f1], f[f0], r[rn], r[ro]};
         FDW_TRY(s->pre(4, four));
         const bool split_last = s->overlap && s->world > 1 && kk == s->ksteps && more;
-        for (int j = 1; j <= kk; j++) {
-            const int r0 = s->has_lo ? h * j : 0, r1 = nxl - (s->has_hi ? h * j : 0);
-            if (split_last && j == kk) {
+        int j = 1;      // position in the cycle: the rows still valid before iteration j are [h (j-1), nxl - h (j-1)) on the interior sides
+        while (j <= kk) {
+            const bool four_now = s->back_pipe && it >= 2 && kk - j + 1 >= kPipe;
+            const int n = four_now ? kPipe : 1;
+            const bool last = j + n - 1 == kk;
+            const int r0 = s->has_lo ? h * (j + n - 1) : 0, r1 = nxl - (s->has_hi ? h * (j + n - 1) : 0);
+            if (four_now) pick_spares();
+            if (split_last && last) {
                 const int lo_end = s->has_lo ? r0 + G : r0, hi_beg = s->has_hi ? r1 - G : r1;
-                FDW_TRY(iter(r0, lo_end));
-                FDW_TRY(iter(hi_beg, r1));
-                float* nxt[4] = {it >= 2 ? f0 : f1, it >= 2 ? f1 : f0, ro, rn};      // the roles the next iteration sees
+                float* nxt[4];
+                if (four_now) {
+                    int a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+                    if (s->has_lo) { a0 = r0; a1 = lo_end; }
+                    if (s->has_hi) { b0 = hi_beg; b1 = r1; }
+                    if (!s->has_lo) { a0 = b0; a1 = b1; b0 = b1 = 0; }
+                    FDW_TRY(pass(a0, a1, b0, b1, 23));
+                    nxt[0] = f[o2]; nxt[1] = f[o1]; nxt[2] = r[q2]; nxt[3] = r[q1];
+                } else {
+                    FDW_TRY(iter(r0, lo_end));
+                    FDW_TRY(iter(hi_beg, r1));
+                    nxt[0] = it >= 2 ? f[f0] : f[f1]; nxt[1] = it >= 2 ? f[f1] : f[f0]; nxt[2] = r[ro]; nxt[3] = r[rn];      // the roles the next iteration sees
+                }
                 FDW_TRY(s->exchange(4, nxt));
-                FDW_TRY(iter(lo_end, hi_beg));
+                if (four_now) FDW_TRY(pass(lo_end, hi_beg, 0, 0, 0));
+                else FDW_TRY(iter(lo_end, hi_beg));
             } else {
-                FDW_TRY(iter(r0, r1));
+                if (four_now) FDW_TRY(pass(r0, r1, 0, 0, 0));
+                else FDW_TRY(iter(r0, r1));
             }
-            advance();
+            if (four_now) {
+                f0 = o1; f1 = o2; ro = q1; rn = q2;
+            } else {
+                if (it >= 2) std::swap(f1, f0);      // F_k was written over F_{k-2}
+                std::swap(rn, ro);                   // R:331-333
+            }
+            it += n;
+            j += n;
         }
         done += kk;
     }
-    if (fswap) *fswap = (f1 == f[1]) ? 1 : 0;
-    if (rswap) *rswap = (rn == r[1]) ? 1 : 0;
+    role[0] = f1; role[1] = f0; role[2] = rn; role[3] = ro;
     return FDW_OK;
 }
 
@@ -377,7 +431,11 @@ extern "C" int fdw_slabs_shot(fdw_slabs* s, const float* v2, int sx, int sz, int
     const int nt = p.nt, nx = p.nxe - 2 * p.nxb, nz = p.nze - 2 * p.nzb, nze = p.nze;
     if (nx <= 0 || nz <= 0) return fdw_fail(FDW_EINVAL, "no interior to image");
     const size_t fe = (size_t)s->nxl * s->pitch;
-    for (int i = 0; i < 6; i++) FDW_TRY(ensure(&s->fld[i], fe));
+    // fields: the forward loop's rotating buffers [0, nbuf) double as the source-field buffers of the backward loop (+ 2 level buffers where it is
+    // pipelined), then the receiver buffers
+    const int nfb = s->back_pipe ? 6 : 2, nrb = s->back_pipe ? 4 : 2, nfwd = std::max(s->nbuf, s->back_pipe ? 4 : 2);
+    const int nfield = std::max(nfwd, nfb) + nrb;
+    for (int i = 0; i < nfield; i++) FDW_TRY(ensure(&s->fld[i], fe));
     FDW_TRY(ensure(&s->d_v2, fe));
     FDW_TRY(ensure(&s->d_img, fe));
     if (s->srce_cap < (size_t)nt) {
@@ -397,7 +455,7 @@ extern "C" int fdw_slabs_shot(fdw_slabs* s, const float* v2, int sx, int sz, int
     HIP_TRY(hipMemsetAsync(s->d_v2, 0, fe * sizeof(float), st));
     HIP_TRY(hipMemcpy2DAsync(s->d_v2, (size_t)s->pitch * sizeof(float), v2 + (size_t)s->x_off * nze, (size_t)nze * sizeof(float), (size_t)nze * sizeof(float),
                              s->nxl, hipMemcpyHostToDevice, st));
-    for (int i = 0; i < 6; i++) HIP_TRY(hipMemsetAsync(s->fld[i], 0, fe * sizeof(float), st));      // R:496-497, R:511-514
+    for (int i = 0; i < nfield; i++) HIP_TRY(hipMemsetAsync(s->fld[i], 0, fe * sizeof(float), st));      // R:496-497, R:511-514
     HIP_TRY(hipMemsetAsync(s->d_img, 0, fe * sizeof(float), st));
     HIP_TRY(hipMemcpyAsync(s->d_srce, srce, (size_t)nt * sizeof(float), hipMemcpyHostToDevice, st));
     // the gather as the backward loop reads it: row it = d_obs[.][nt-1-it] (R:124-131 with the time reversal of R:328)
@@ -423,17 +481,11 @@ extern "C" int fdw_slabs_shot(fdw_slabs* s, const float* v2, int sx, int sz, int
     };
     if (P) HIP_TRY(download_owned(P, snaps[0]));
     if (PP) HIP_TRY(download_owned(PP, snaps[1]));
-    float* rcv[2] = {nullptr, nullptr};
-    if (s->nbuf == 4) {      // the two forward buffers that do not hold the snapshots carry stale rows: the receiver pair starts from zero (R:513-514)
-        rcv[0] = s->fld[4];
-        rcv[1] = s->fld[5];
-    } else {
-        rcv[0] = s->fld[2];
-        rcv[1] = s->fld[3];
-    }
+    // backward loop: source-field buffers = fld[0 .. max(nfwd, nfb)) with the snapshots where the forward loop left them; receiver buffers behind
+    float** rbuf = s->fld + std::max(nfwd, nfb);
     s->fresh = false;       // the ghosts of the finalized snapshot and of the receiver pair have to travel once
-    int fswap = 0, rswap = 0;
-    FDW_TRY(fdw_slabs_dev_back(s, snaps, rcv, s->d_v2, s->d_samples, gz, s->d_img, 0, nt, &fswap, &rswap));
+    int role[4] = {ip, ipp, 0, 1};
+    FDW_TRY(fdw_slabs_dev_back(s, s->fld, rbuf, s->d_v2, s->d_samples, gz, s->d_img, 0, nt, role));
     const int w0 = std::max(s->o0, p.nxb), w1 = std::min(s->o1, p.nxb + nx);       // owned interior rows
     if (w1 > w0)
         HIP_TRY(hipMemcpy2DAsync(imloc + (size_t)(w0 - p.nxb) * nz, (size_t)nz * sizeof(float), s->d_img + s->row(w0 - s->x_off) + p.nzb,

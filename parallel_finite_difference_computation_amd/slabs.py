@@ -102,11 +102,18 @@ class Slabs:
         check(lib().fdw_slabs_dev_forward(self._h, arr, d_v2, d_srce, sx, sz, it0, nsteps, int(first_pp_twice), C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def dev_back(self, f, r, d_v2, d_samples, gz, d_img, it0, nsteps, fswap=0, rswap=0):
-        fa, ra = (C.c_void_p * 2)(*f), (C.c_void_p * 2)(*r)
-        a, b = C.c_int(fswap), C.c_int(rswap)
-        check(lib().fdw_slabs_dev_back(self._h, fa, ra, d_v2, d_samples, gz, d_img, it0, nsteps, C.byref(a), C.byref(b)))
+    def back_buffers(self):
+        """(nfb, nrb): source-field and receiver-field buffers fdw_slabs_dev_back works on (6 and 4 with the wave pipeline, else 2 and 2)."""
+        a, b = C.c_int(), C.c_int()
+        check(lib().fdw_slabs_back_buffers(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def dev_back(self, f, r, d_v2, d_samples, gz, d_img, it0, nsteps, role=(0, 1, 0, 1)):
+        """fd_back's loop on the slab; role = indices of (F_{k-1}, F_{k-2}) in f and (r^k, r^{k-1}) in r; returns the roles after the loop."""
+        fa, ra = (C.c_void_p * len(f))(*f), (C.c_void_p * len(r))(*r)
+        ro = (C.c_int * 4)(*role)
+        check(lib().fdw_slabs_dev_back(self._h, fa, ra, d_v2, d_samples, gz, d_img, it0, nsteps, ro))
+        return tuple(ro)
 
     def taper_finalize(self, d_f):
         check(lib().fdw_dev_taper_finalize(self._ctx_h, d_f, self.stream))

@@ -22,7 +22,8 @@ NB = 64
 def run(world, ksteps, back):
     comm = F.Comm.stub(world // 2, world) if world > 1 else None
     sl = F.Slabs(8, n, n, NB, NB, K, 0.75, 10.0, 10.0, 1e-3, comm=comm, compat=False, ksteps=ksteps)
-    fl = [1e-3 * torch.randn((sl.nxl, sl.pitch), device=dev) for _ in range(sl.nbuf + 2)]
+    nfb, nrb = sl.back_buffers()
+    fl = [1e-3 * torch.randn((sl.nxl, sl.pitch), device=dev) for _ in range(max(sl.nbuf, nfb) + nrb)]
     for f in fl:
         f[:, n:] = 0
     v2 = torch.zeros((sl.nxl, sl.pitch), device=dev)
@@ -36,7 +37,7 @@ def run(world, ksteps, back):
     for rep in range(4):
         t0 = time.perf_counter()
         if back:
-            sl.dev_back([fl[0].data_ptr(), fl[1].data_ptr()], [fl[-2].data_ptr(), fl[-1].data_ptr()], v2.data_ptr(), smp.data_ptr(), NB + 3, img.data_ptr(), 2, K - 2)
+            sl.dev_back([f.data_ptr() for f in fl[:max(sl.nbuf, nfb)]], [f.data_ptr() for f in fl[max(sl.nbuf, nfb):]], v2.data_ptr(), smp.data_ptr(), NB + 3, img.data_ptr(), 2, K - 2)
         else:
             sl.dev_forward(ptrs, v2.data_ptr(), srce.data_ptr(), n // 2, n // 2, 0, K, True, 0, 1)
         sl.synchronize()
@@ -51,6 +52,6 @@ def run(world, ksteps, back):
 for back in (False, True):
     base = run(1, 0, back)
     for world in (2, 4, 8):
-        for k in ((0,) if not back else (4, 8)):
+        for k in ((0,) if not back else (8, 16)):
             v = run(world, k, back)
             print(f"    -> {v / base:5.2f} x the one-GPU figure", flush=True)
