@@ -42,15 +42,22 @@ ORDER, NB, FAC, DX, DT, FPEAK = 8, 64, 0.75, 10.0, 1.0e-3, 20.0
 MIN_TIMED_SECONDS = 0.3       # the K-step window is repeated until this much time has been measured; the median window is reported
 
 
-def kernel_source_hash():
-    """Identifies the built kernels: profiles/traffic.json (rocprofv3 --pmc passes taken offline) is only quoted for the sources it was taken on."""
-    import glob
+KERNEL_SOURCES = {      # the translation units behind each workload's dominant kernel (+ the shared device header and argument structs)
+    "forward": ("fdw_stepn.hip", "fdw_step2.hip", "fdw_device.h", "fdw_kernels.h"),
+    "model": ("fdw_stepn.hip", "fdw_device.h", "fdw_kernels.h"),
+    "rtm-slab": ("fdw_stepn.hip", "fdw_device.h", "fdw_kernels.h"),
+    "stencil": ("fdw_step1.hip", "fdw_device.h", "fdw_kernels.h"),
+}
+
+
+def kernel_source_hash(workload="forward"):
+    """Identifies the built kernel: profiles/traffic.json (rocprofv3 --pmc passes taken offline) is only quoted for the sources it was taken on."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "parallel_finite_difference_computation_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + [os.path.join(csrc, "fdw_device.h"), os.path.join(csrc, "fdw_kernels.h")]):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for f in KERNEL_SOURCES.get(workload, KERNEL_SOURCES["forward"]):
+        h.update(f.encode())
+        h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -62,7 +69,7 @@ def offline_counters(workload, n, steps_per_launch):
         return None
     if isinstance(entries, dict):
         entries = [entries]
-    want = kernel_source_hash()
+    want = kernel_source_hash(workload)
     for e in entries:
         if e.get("workload", "forward") == workload and e.get("size") == n and e.get("steps_per_launch", 1) == steps_per_launch and e.get("source_hash") == want:
             return e

@@ -237,3 +237,24 @@ void orc_image_laplacian(const float *img, int nx, int nz, float dx, float dz, f
             out[k] = ((img[k + 1] - 2.f * c) + img[k - 1]) / (dz * dz) + ((img[k + nz] - 2.f * c) + img[k - nz]) / (dx * dx);
         }
 }
+
+/* ---- the reference's image comparer models/marmousi/psnr (an x86-64 ELF without source; "Usage: ./psnr file1 file2") -------------------
+ * Restated from the tool's observable behaviour and pinned to its own output (tests/golden/psnr_reference_output.json, produced by running
+ * the binary): the squares (formed in double) are added one after the other into fp32 sums, MSE = sum / n in fp32, RMSE = sqrtf, SNR = 10 log10(sum f2^2 / sum d^2),
+ * PSNR = 20 log10(max |f2| / RMSE) narrowed to fp32; d = f1 - f2 is what it writes to ./dir.output.  stats = {MSE, RMSE, SNR, PSNR}. */
+void orc_image_compare(const float *f1, const float *f2, size_t n, float *diff, double *stats)
+{
+    float sd = 0.0f, sb = 0.0f, mx = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        const float d = f1[i] - f2[i];
+        if (diff) diff[i] = d;
+        sd = (float)((double)sd + (double)d * (double)d);      /* the squares are formed in double (pow-like), the running sums kept in fp32 */
+        sb = (float)((double)sb + (double)f2[i] * (double)f2[i]);
+        if (fabsf(f2[i]) > mx) mx = fabsf(f2[i]);
+    }
+    const float mse = sd / (float)n, rmse = sqrtf(mse);
+    stats[0] = mse;
+    stats[1] = rmse;
+    stats[2] = 10.0 * log10((double)(sb / sd));
+    stats[3] = (float)(20.0 * log10((double)(mx / rmse)));      /* the tool keeps this one in a float (its last printed digit shows it) */
+}

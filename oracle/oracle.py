@@ -79,6 +79,7 @@ def _declare(L):
     L.orc_mod_shot.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p]
     L.orc_mod_taper_apply2.argtypes = [f32p] + [C.c_int] * 4 + [f32p, f32p]
     L.orc_image_laplacian.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p]
+    L.orc_image_compare.argtypes = [f32p, f32p, C.c_size_t, C.c_void_p, C.POINTER(C.c_double)]
     L.orc_rtm_stored_shot.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_size_t, C.c_int, f32p]
     return L
 
@@ -236,6 +237,20 @@ def image_laplacian(img, dx, dz):
     out = np.zeros_like(img)
     lib().orc_image_laplacian(img, img.shape[0], img.shape[1], dx, dz, out)
     return out
+
+
+def image_compare(a, b, want_diff=False):
+    """The reference's `./psnr file1 file2`: (mse, rmse, snr, psnr) and optionally the difference a - b."""
+    a, b = np.ascontiguousarray(a, np.float32).ravel(), np.ascontiguousarray(b, np.float32).ravel()
+    st = (C.c_double * 4)()
+    diff = np.zeros_like(a) if want_diff else None
+    lib().orc_image_compare(a, b, a.size, diff.ctypes.data if want_diff else None, st)
+    return (tuple(st), diff) if want_diff else tuple(st)
+
+
+def psnr_lines(stats):
+    """The four lines the reference tool prints for these values."""
+    return "".join("%-10s %15e\n" % (k, v) for k, v in zip(("MSE:", "RMSE:", "SNR:", "PSNR:"), stats))
 
 
 def ref_lapfilt():

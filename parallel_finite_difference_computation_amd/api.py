@@ -83,6 +83,18 @@ def image_laplacian(img, dx, dz, device=0):
     return out
 
 
+def image_compare(a, b, device=0, want_diff=False):
+    """The reference's `./psnr file1 file2` (models/marmousi/psnr) on the GPU: dict(mse, rmse, snr, psnr) and, if asked, the difference a - b."""
+    a, b = np.ascontiguousarray(a, np.float32).ravel(), np.ascontiguousarray(b, np.float32).ravel()
+    if a.size != b.size:
+        raise ValueError("sizes differ")
+    st = (C.c_double * 4)()
+    diff = np.zeros_like(a) if want_diff else None
+    check(lib().fdw_image_compare(device, a, b, a.size, diff.ctypes.data if want_diff else None, st))
+    out = dict(mse=st[0], rmse=st[1], snr=st[2], psnr=st[3])
+    return (out, diff) if want_diff else out
+
+
 class FDWave:
     """One fd_init (fd-code.cu:200-224 / fd-source-code.cu:241-262) worth of state on one MI355X."""
 

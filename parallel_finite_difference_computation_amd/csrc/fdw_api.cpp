@@ -1311,6 +1311,42 @@ extern "C" int fdw_image_laplacian(int device, const float* img, int nx, int nz,
     return rc;
 }
 
+// The reference's image comparer models/marmousi/psnr (an ELF without source; behaviour read off its output: MSE = mean (a-b)^2, RMSE, SNR =
+// 10 log10(sum b^2 / sum (a-b)^2), PSNR = 20 log10(max |b| / RMSE), the difference a - b written out) on the device.
+extern "C" int fdw_image_compare(int device, const float* a, const float* b, size_t n, float* diff, double stats[4])
+{
+    if (!a || !b || !stats || n == 0) return fail(FDW_EINVAL, "image_compare: bad argument");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || device < 0 || device >= ndev)
+        return fail(FDW_ENODEVICE, "image_compare: no HIP device %d (%s); libfdwave has no CPU path", device, e != hipSuccess ? hipGetErrorString(e) : "out of range");
+    HIP_TRY(hipSetDevice(device));
+    const int nblocks = (int)std::min<size_t>(1024, (n + 255) / 256);
+    float *d_a = nullptr, *d_b = nullptr, *d_d = nullptr;
+    double* d_w = nullptr;
+    const size_t bytes = n * sizeof(float);
+    int rc = FDW_OK;
+    if (hipMalloc((void**)&d_a, bytes) != hipSuccess || hipMalloc((void**)&d_b, bytes) != hipSuccess || (diff && hipMalloc((void**)&d_d, bytes) != hipSuccess) ||
+        hipMalloc((void**)&d_w, (3 * (size_t)nblocks + 3) * sizeof(double)) != hipSuccess)
+        rc = fail(FDW_ENOMEM, "image_compare: hipMalloc failed");
+    double h[3] = {0, 0, 0};
+    if (rc == FDW_OK) {
+        if ((e = hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice)) != hipSuccess || (e = hipMemcpy(d_b, b, bytes, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = launch_image_compare(d_a, d_b, n, d_d, d_w + 3, nblocks, d_w, nullptr)) != hipSuccess ||
+            (e = hipMemcpy(h, d_w, sizeof h, hipMemcpyDeviceToHost)) != hipSuccess || (diff && (e = hipMemcpy(diff, d_d, bytes, hipMemcpyDeviceToHost)) != hipSuccess))
+            rc = fail(FDW_EHIP, "image_compare: %s", hipGetErrorString(e));
+    }
+    for (void* p : {(void*)d_a, (void*)d_b, (void*)d_d, (void*)d_w})
+        if (p) (void)hipFree(p);
+    if (rc != FDW_OK) return rc;
+    const double mse = h[0] / (double)n, rmse = std::sqrt(mse);
+    stats[0] = mse;
+    stats[1] = rmse;
+    stats[2] = 10.0 * std::log10(h[1] / h[0]);
+    stats[3] = 20.0 * std::log10(h[2] / rmse);
+    return FDW_OK;
+}
+
 extern "C" int fdw_get_tables(const fdw_ctx* c, float* coefs_x, float* coefs_z, float* taper_x, float* taper_z)
 {
     if (!c) return fail(FDW_EINVAL, "ctx is NULL");

@@ -120,15 +120,6 @@ extern "C" int fdw_slabs_create(const fdw_params* prm, fdw_comm* comm, int devic
     if (const char* e = getenv("FDW_COMM_STUB")) s->stub = atoi(e) != 0;      // timing experiments only: the cycles without the transfers
     if (const char* e = getenv("FDW_SLAB_NO_OVERLAP")) s->overlap = atoi(e) == 0;
     slab_bounds(prm->nxe, s->world, s->rank, &s->o0, &s->o1);
-    if (s->world > 1 && ksteps <= 0) {
-        // One exchange costs a few tens of microseconds of enqueue and link latency whatever its size: let a cycle last >= ~400 us of GPU
-        // time, k = 400 us / (slab points / ~350 Gpoints/s), whole passes of four steps, at most 16 (redundant ghost work h (k-1) / 2 rows
-        // per side and step: 4.7 % of a 1024-row slab at k = 16)
-        const double t_step_us = (double)(prm->nxe / s->world) * prm->nze / 350e9 * 1e6;
-        ksteps = (int)std::max(4.0, std::min(16.0, 4.0 * std::ceil(400.0 / std::max(t_step_us, 1e-3) / 4.0)));
-    }
-    s->ksteps = s->world > 1 ? std::max(ksteps, 1) : 1;
-    s->G = s->h * s->ksteps;
     // every rank must take the same decisions: the thinnest band bounds the ghost width
     int min_own = prm->nxe;
     for (int r = 0; r < s->world; r++) {
@@ -136,6 +127,17 @@ extern "C" int fdw_slabs_create(const fdw_params* prm, fdw_comm* comm, int devic
         slab_bounds(prm->nxe, s->world, r, &a, &b);
         min_own = std::min(min_own, b - a);
     }
+    if (s->world > 1 && ksteps <= 0) {
+        // One exchange costs a few tens of microseconds of enqueue and link latency whatever its size: let a cycle last >= ~400 us of GPU
+        // time, k = 400 us / (slab points / ~350 Gpoints/s), whole passes of four steps, at most 16 (redundant ghost work h (k-1) / 2 rows
+        // per side and step: 4.7 % of a 1024-row slab at k = 16) -- and no more than a thin band can carry with its two boundary strips apart
+        const double t_step_us = (double)(prm->nxe / s->world) * prm->nze / 350e9 * 1e6;
+        ksteps = (int)std::max(4.0, std::min(16.0, 4.0 * std::ceil(400.0 / std::max(t_step_us, 1e-3) / 4.0)));
+        const int fit = (min_own - 4 * s->h) / (2 * s->h);
+        if (ksteps > fit) ksteps = fit >= 4 ? (fit / 4) * 4 : std::max(fit, 1);
+    }
+    s->ksteps = s->world > 1 ? std::max(ksteps, 1) : 1;
+    s->G = s->h * s->ksteps;
     if (s->world > 1 && min_own < s->G) {
         const int owned = s->o1 - s->o0, G = s->G;
         delete s;

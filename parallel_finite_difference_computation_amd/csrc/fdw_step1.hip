@@ -555,6 +555,66 @@ hipError_t launch_taper_finalize(float* f, const float* taperz, const float* txf
     return hipGetLastError();
 }
 
+// ---- image comparison (the reference's offline tool models/marmousi/psnr: "./psnr file1 file2") ----------------------------------------
+// diff = a - b (fp32, as the tool writes it to dir.output); per block: sums of the squares (a-b)^2 and b^2 in double, max |b|.
+// The tool itself adds the squares one after the other into fp32 sums; a parallel reduction cannot reproduce that order, so the sums here are
+// those of the same terms carried in double (they differ from the tool's in the 6th-7th digit, where the tool carries its rounding).
+__global__ __launch_bounds__(256) void fdw_image_compare_kernel(const float* a, const float* b, size_t n, float* diff, double* part)
+{
+    __shared__ double sh[3][256];
+    double sd = 0.0, sb = 0.0, mx = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float x = a[i], y = b[i];
+        const float d = x - y;
+        if (diff) diff[i] = d;
+        sd += (double)d * (double)d;
+        sb += (double)y * (double)y;
+        mx = fmax(mx, (double)fabsf(y));
+    }
+    sh[0][threadIdx.x] = sd; sh[1][threadIdx.x] = sb; sh[2][threadIdx.x] = mx;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + w];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + w];
+            sh[2][threadIdx.x] = fmax(sh[2][threadIdx.x], sh[2][threadIdx.x + w]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 3 + 0] = sh[0][0];
+        part[blockIdx.x * 3 + 1] = sh[1][0];
+        part[blockIdx.x * 3 + 2] = sh[2][0];
+    }
+}
+__global__ __launch_bounds__(256) void fdw_image_compare_final_kernel(const double* part, int nblocks, double* out)
+{
+    __shared__ double sh[3][256];
+    double sd = 0.0, sb = 0.0, mx = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        sd += part[i * 3];
+        sb += part[i * 3 + 1];
+        mx = fmax(mx, part[i * 3 + 2]);
+    }
+    sh[0][threadIdx.x] = sd; sh[1][threadIdx.x] = sb; sh[2][threadIdx.x] = mx;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + w];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + w];
+            sh[2][threadIdx.x] = fmax(sh[2][threadIdx.x], sh[2][threadIdx.x + w]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; out[2] = sh[2][0]; }
+}
+hipError_t launch_image_compare(const float* a, const float* b, size_t n, float* diff, double* d_part, int nblocks, double* d_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(fdw_image_compare_kernel, dim3(nblocks), dim3(256), 0, s, a, b, n, diff, d_part);
+    hipLaunchKernelGGL(fdw_image_compare_final_kernel, dim3(1), dim3(256), 0, s, d_part, nblocks, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_image_laplacian(const float* d_img, float* d_out, int nx, int nz, float dx, float dz, hipStream_t s)
 {
     hipLaunchKernelGGL(fdw_image_lap_kernel, dim3((nz + 255) / 256, nx), dim3(256), 0, s, d_img, d_out, nx, nz, dx, dz);

@@ -7,7 +7,12 @@
  * (fd_forward + fd_back, R:499-518) is one device-resident fdw_shot() call; launch extents are the
  * reference's (compat = 1), so the image equals the reference's.  Shots run side by side on up to FDW_SHOT_WORKERS (default 4) host
  * threads / streams; models are drawn and images stacked in shot order, so every output is what the serial loop writes.
- * Not reproduced: the `file-teste` debug dump at it == 750 (R:268-281) and the in-loop progress lines. */
+ * Not reproduced: the `file-teste` debug dump at it == 750 (R:268-281) and the in-loop progress lines.
+ *
+ * Several GPUs (no counterpart in the reference, which drives one): the deck key `slabs=N` (or FDW_SLABS=N in the environment) runs every
+ * shot on N GPUs, the grid cut into N bands of rows with halo exchange over RCCL / xGMI inside libfdwave.so (fdw_slabs_shot), one host
+ * thread per GPU; FDW_SLABS_LOCAL=1 keeps all N ranks on GPU 0 with device copies instead of RCCL (tests on a one-GPU box).  `gpus=N` (or
+ * FDW_GPUS=N) deals whole shots to N GPUs instead.  Every output file is byte for byte the one-GPU program's. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -51,6 +56,7 @@ typedef struct {
     int dev_border;
     float *imloc_all;
     size_t ne, ni;
+    int gpus;             /* workers are dealt to GPUs 0 .. gpus-1 */
     volatile int failed;
 } shot_job;
 typedef struct {
@@ -63,7 +69,7 @@ static void *shot_worker(void *p)
     shot_worker_arg *a = (shot_worker_arg *)p;
     shot_job *j = a->job;
     fdw_ctx *ctx = NULL;
-    if (fdw_create(j->prm, 0, &ctx) != FDW_OK) { /* fd_init, R:452 (one context = one stream + its own device buffers per worker) */
+    if (fdw_create(j->prm, a->w % (j->gpus > 0 ? j->gpus : 1), &ctx) != FDW_OK) { /* fd_init, R:452 (one context = one stream + its own device buffers per worker) */
         fprintf(stderr, "fdw_create: %s\n", fdw_last_error());
         j->failed = 1;
         return NULL;
@@ -90,6 +96,63 @@ static void *shot_worker(void *p)
         }
     }
     fdw_destroy(ctx);
+    return NULL;
+}
+
+/* ---- slabs=N: every shot decomposed over N ranks (host threads, one GPU each) ---------------------------------------------- */
+typedef struct {
+    const fdw_params *prm;
+    int world, local, ns, nx, nt, sz, gz;
+    const int *sx;
+    const float *srce, *d_obs;
+    const float *v2;         /* the current shot's squared model [nxe][nze], built by rank 0 between the barriers */
+    float *imloc;            /* the current shot's image [nx][nz]: every rank writes its own rows */
+    char uid[FDW_COMM_ID_BYTES];
+    fdw_comm **local_comms;
+    pthread_barrier_t *bar;
+    volatile int failed;
+} slab_job;
+typedef struct {
+    slab_job *job;
+    int rank;
+    fdw_comm *comm;
+    fdw_slabs *slabs;
+} slab_rank;
+
+static int slab_rank_open(slab_rank *r)
+{
+    slab_job *j = r->job;
+    int rc = FDW_OK;
+    if (j->local) r->comm = j->local_comms[r->rank];
+    else rc = fdw_comm_init_rank(j->uid, r->rank, j->world, r->rank, &r->comm);      /* rank r drives GPU r */
+    if (rc == FDW_OK) rc = fdw_slabs_create(j->prm, r->comm, 0, 0, &r->slabs);
+    if (rc != FDW_OK) {
+        fprintf(stderr, "rank %d: %s\n", r->rank, fdw_last_error());
+        j->failed = 1;
+    }
+    return rc;
+}
+static void slab_rank_shot(slab_rank *r, int is)
+{
+    slab_job *j = r->job;
+    if (j->failed || !r->slabs) return;
+    if (fdw_slabs_shot(r->slabs, j->v2, j->sx[is], j->sz, j->gz, j->srce, j->d_obs + (size_t)is * j->nx * j->nt, j->imloc, NULL, NULL) != FDW_OK) {
+        fprintf(stderr, "rank %d, shot %d: %s\n", r->rank, is, fdw_last_error());
+        j->failed = 1;
+    }
+}
+static void *slab_rank_thread(void *p)      /* ranks 1 .. N-1; rank 0 is the main thread */
+{
+    slab_rank *r = (slab_rank *)p;
+    slab_job *j = r->job;
+    slab_rank_open(r);
+    for (int is = 0; is < j->ns; is++) {
+        pthread_barrier_wait(j->bar);       /* A: the shot's model is ready */
+        slab_rank_shot(r, is);
+        pthread_barrier_wait(j->bar);       /* B: every rank's rows of the image are in place */
+    }
+    if (r->slabs) fdw_slabs_destroy(r->slabs);
+    if (r->comm) fdw_comm_destroy(r->comm);
     return NULL;
 }
 
@@ -187,10 +250,66 @@ int main(int argc, char **argv)
     /* The border model itself is generated on the device from the resident interior model (fdw_dev_extendvel_linear: the rand() stream is
      * addressed by position, so no worker waits for another's draws); FDW_HOST_BORDER=1 or a geometry the device path refuses (a one-cell
      * border) keeps the host loop below. */
+    int slabs = fdw_deck_int(deck, "slabs"), gpus = fdw_deck_int(deck, "gpus");      /* our extensions; absent = -1 */
+    if (getenv("FDW_SLABS")) slabs = atoi(getenv("FDW_SLABS"));
+    if (getenv("FDW_GPUS")) gpus = atoi(getenv("FDW_GPUS"));
+    if (slabs > 64 || gpus > 64) {
+        fprintf(stderr, "slabs / gpus: at most 64\n");
+        return EXIT_FAILURE;
+    }
+    if (slabs > 1) {
+        /* ---- every shot on `slabs` GPUs: bands of rows, halo exchange inside the library ---- */
+        slab_job sj;
+        memset(&sj, 0, sizeof sj);
+        sj.prm = &prm; sj.world = slabs; sj.local = getenv("FDW_SLABS_LOCAL") != NULL; sj.ns = ns; sj.nx = nx; sj.nt = nt; sj.sz = sz; sj.gz = gz;
+        sj.sx = sx; sj.srce = srce; sj.d_obs = d_obs;
+        float *v2 = (float *)malloc(ne * sizeof(float)), *imloc = (float *)calloc(ni, sizeof(float));
+        fdw_comm *lc[64];
+        pthread_barrier_t bar;
+        pthread_t th[64];
+        slab_rank rk[64];
+        if (!v2 || !imloc || pthread_barrier_init(&bar, NULL, (unsigned)slabs) != 0) return EXIT_FAILURE;
+        sj.imloc = imloc; sj.v2 = v2; sj.bar = &bar; sj.local_comms = lc;
+        if ((sj.local ? fdw_comm_init_local(slabs, NULL, lc) : fdw_comm_get_unique_id(sj.uid)) != FDW_OK) {
+            fprintf(stderr, "communicator: %s\n", fdw_last_error());
+            return EXIT_FAILURE;
+        }
+        for (int r = 0; r < slabs; r++) {
+            memset(&rk[r], 0, sizeof rk[r]);
+            rk[r].job = &sj; rk[r].rank = r;
+            if (r > 0 && pthread_create(&th[r], NULL, slab_rank_thread, &rk[r]) != 0) return EXIT_FAILURE;
+        }
+        slab_rank_open(&rk[0]);
+        for (int is = 0; is < ns; is++) {
+            const float *v = vpe;
+            if (vel_ext_flag) v = vel_ext_rnd + (size_t)is * ne;      /* R:484 */
+            else fdw_extendvel_linear(nx, nz, nxb, nzb, vpe);         /* R:486 */
+            for (size_t k = 0; k < ne; k++) v2[k] = v[k] * v[k];      /* R:490-494 */
+            memset(imloc, 0, ni * sizeof(float));                     /* R:515 */
+            pthread_barrier_wait(&bar);
+            slab_rank_shot(&rk[0], is);
+            pthread_barrier_wait(&bar);
+            fprintf(stdout, "** source %d, at (%d,%d) \n\n** backward propagation %d, at (%d,%d) \n\n", is + 1, sx[is] - nxb, sz - nzb, is + 1, sx[is] - nxb, sz - nzb);
+            fprintf(fnum, "======== %i ========\n", is);
+            for (int iz = 0; iz < nz; iz++)
+                for (int ix = 0; ix < nx; ix++) {
+                    img[(size_t)ix * nz + iz] += imloc[(size_t)ix * nz + iz];
+                    fprintf(fnum, " %f \n", img[(size_t)ix * nz + iz]);
+                }
+        }
+        for (int r = 1; r < slabs; r++) pthread_join(th[r], NULL);
+        if (rk[0].slabs) fdw_slabs_destroy(rk[0].slabs);
+        if (rk[0].comm) fdw_comm_destroy(rk[0].comm);
+        pthread_barrier_destroy(&bar);
+        free(v2); free(imloc);
+        if (sj.failed) return EXIT_FAILURE;
+        goto outputs;
+    }
     const int dev_border = !vel_ext_flag && !getenv("FDW_HOST_BORDER") && nxb != 1 && nzb != 1 && nzb <= nxe;
     int nworkers = 4;
     if (getenv("FDW_SHOT_WORKERS")) nworkers = atoi(getenv("FDW_SHOT_WORKERS"));
     if (nworkers < 1) nworkers = 1;
+    if (gpus > 1 && nworkers < gpus) nworkers = gpus;      /* at least one worker per GPU */
     if (nworkers > ns) nworkers = ns;
     if (nworkers > 64) nworkers = 64;
     while (nworkers > 1 && (size_t)ns * (ne + ni) * sizeof(float) > ((size_t)8 << 30)) nworkers = 1;   /* big decks: one shot fills the GPU anyway */
@@ -198,7 +317,7 @@ int main(int argc, char **argv)
      * the chip for this geometry, 1 = the grid is big enough by itself).  FDW_NO_SHOT_BATCH=1 keeps one shot per launch sequence. */
     fdw_ctx *bctx = NULL;
     int bmax = 1;
-    if (ns > 1 && !getenv("FDW_NO_SHOT_BATCH")) {
+    if (ns > 1 && !getenv("FDW_NO_SHOT_BATCH") && gpus <= 1) {      /* (shots dealt to several GPUs go one context per worker instead) */
         if (fdw_create(&prm, 0, &bctx) != FDW_OK) {
             fprintf(stderr, "fdw_create: %s\n", fdw_last_error());
             return EXIT_FAILURE;
@@ -223,7 +342,7 @@ int main(int argc, char **argv)
     shot_job job;
     job.prm = &prm; job.ns = ns; job.nworkers = nworkers; job.sx = sx; job.sz = sz; job.gz = gz; job.srce = srce; job.d_obs = d_obs;
     job.nx = nx; job.nt = nt; job.ne = ne; job.ni = ni; job.vel2_all = vel2_all; job.imloc_all = imloc_all; job.failed = 0;
-    job.vp = vp; job.draws = fdw_border_draws(nx, nz, nxb, nzb); job.dev_border = dev_border;
+    job.vp = vp; job.draws = fdw_border_draws(nx, nz, nxb, nzb); job.dev_border = dev_border; job.gpus = gpus;
 
     for (int is0 = 0; is0 < ns; is0 += batch) {
         const int nb = is0 + batch <= ns ? batch : ns - is0;
@@ -281,6 +400,10 @@ int main(int argc, char **argv)
         }
         t_stack += now_s() - t1;
     }
+    if (bctx) fdw_destroy(bctx);
+    free(vel2_all);
+    free(imloc_all);
+outputs:
     if (timing)
         fprintf(stderr, "[timing] total %.3f s: shots (contexts, border models, propagation) %.3f s, stacking + image.num %.3f s, rest (deck, inputs) %.3f s\n",
                 now_s() - t_begin, t_shots, t_stack, now_s() - t_begin - t_shots - t_stack);
@@ -303,9 +426,8 @@ int main(int argc, char **argv)
     fclose(fimg);
     fclose(fimg_lap);
     fclose(fnum);
-    if (bctx) fdw_destroy(bctx);
-    free(srce); free(sx); free(vel_ext_rnd); free(d_obs); free(vp); free(vpe); free(vel2_all);
-    free(imloc_all); free(img); free(img_lap);
+    free(srce); free(sx); free(vel_ext_rnd); free(d_obs); free(vp); free(vpe);
+    free(img); free(img_lap);
     fdw_deck_free(deck);
     return 0;
 }

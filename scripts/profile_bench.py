@@ -76,7 +76,7 @@ def main():
         if ln.startswith("{") and '"metric"' in ln:
             bench_line = json.loads(ln)
     from bench import kernel_source_hash
-    lines = [f"command: python3 bench.py {' '.join(bench_args)} --no-cpu-baseline   (kernel sources {kernel_source_hash()})", ""]
+    lines = [f"command: python3 bench.py {' '.join(bench_args)} --no-cpu-baseline   (kernel sources {kernel_source_hash(wkey)})", ""]
     entry = None
     for kname in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", [0, 1])[0]):
         c = {k: v[0] / v[1] for k, v in agg[kname].items()}
@@ -105,7 +105,7 @@ def main():
         lines.append("")
         if entry is None and d and bench_line is not None:       # the dominant kernel of the command
             entry = dict(workload=wkey, size=bench_line["config"]["grid"][0], steps_per_launch=bench_line.get("roofline", {}).get("steps_per_launch", 1),
-                         kernel=kname, source_hash=kernel_source_hash(), source=f"profiles/r02_pmc_{tag}.txt", sq_source=f"profiles/r02_pmc_{tag}.txt", **d)
+                         kernel=kname, source_hash=kernel_source_hash(wkey), source=f"profiles/r02_pmc_{tag}.txt", sq_source=f"profiles/r02_pmc_{tag}.txt", **d)
             if st:
                 entry["kernel_trace_avg_us"] = round(float(st["AverageNs"]) / 1e3, 2)
     if bench_line is not None:

@@ -21,6 +21,8 @@ oracle/Makefile from cuda_reference_RTM/lib/src/functions.c).  No reference sour
                               model and decks/dd_3lay_mod.dat (151 traces x 1001 samples) -- known answer of the modelling producer
   dd_3lay_mod_dir_image.f32   dpct_gpu_rtm_domain_division/build/3lay_mod/dir.image: the image its rtm_main formed from that gather
                               (151x151; with ns = 1 the per-shot dir.img is the same bytes) -- known answer of the stored-wavefield RTM
+  psnr_reference_output.json  stdout (and the SHA-256 of ./dir.output) of the reference's own comparer models/marmousi/psnr -- an x86-64 ELF
+                              shipped without source -- run here on pairs of the fixtures above: known answers of bin/psnr / fdw_image_compare
   dd_3lay_mod_dir_imalap.f32  output of the reference's laplace.f90 (built unmodified with flang: oracle/_ref/lapfilt) run on that dir.image
 """
 import ctypes as C
@@ -65,6 +67,28 @@ def main():
         shutil.copyfile(os.path.join(HERE, "dd_3lay_mod_dir_image.f32"), os.path.join(td, "dir.image"))
         subprocess.check_call([lapfilt], cwd=td)
         shutil.copyfile(os.path.join(td, "dir.imalap"), os.path.join(HERE, "dd_3lay_mod_dir_imalap.f32"))
+    # the reference's psnr binary on pairs of committed fixtures (it writes ./dir.output, so it runs in a scratch directory)
+    import hashlib
+    import json
+    cases = []
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "psnr")
+        shutil.copyfile(os.path.join(REF, "cuda_reference_RTM/models/marmousi/psnr"), exe)
+        os.chmod(exe, 0o755)
+        img = np.fromfile(os.path.join(HERE, "dd_3lay_mod_dir_image.f32"), np.float32)
+        noisy = (img + np.float32(0.05) * np.abs(img).max() * np.random.default_rng(7).standard_normal(img.size).astype(np.float32)).astype(np.float32)
+        noisy.tofile(os.path.join(td, "noisy.f32"))
+        for a, b in (("dd_3lay_mod_dir_image.f32", "dd_3lay_mod_dir_imalap.f32"), ("dd_3lay_mod_dir_image.f32", "dd_3lay_mod_dir_image.f32"),
+                     ("noisy.f32", "dd_3lay_mod_dir_image.f32"), ("dd_3lay_mod_dir_image.f32", "noisy.f32")):
+            pa = os.path.join(td if a == "noisy.f32" else HERE, a)
+            pb = os.path.join(td if b == "noisy.f32" else HERE, b)
+            r = subprocess.run([exe, pa, pb], cwd=td, capture_output=True, text=True)
+            cases.append(dict(a=a, b=b, stdout=r.stdout, dir_output_sha256=hashlib.sha256(open(os.path.join(td, "dir.output"), "rb").read()).hexdigest()))
+        for argv in ([], ["/nonexistent", os.path.join(HERE, "dd_3lay_mod_dir_image.f32")], [os.path.join(HERE, "dd_3lay_mod_dir_image.f32"), "/nonexistent"],
+                     [os.path.join(HERE, "dd_3lay_mod_dir_image.f32"), os.path.join(HERE, "new_mod_vel_koslov.f32")]):
+            r = subprocess.run([exe] + argv, cwd=td, capture_output=True, text=True)
+            cases.append(dict(argv=[os.path.basename(x) for x in argv], stdout=r.stdout, returncode=r.returncode))
+    json.dump(dict(noise="noisy.f32 = image + 0.05 max|image| N(0,1), numpy default_rng(7), float32", cases=cases), open(os.path.join(HERE, "psnr_reference_output.json"), "w"), indent=1)
 
     L = O.ref_lib()
     assert L is not None, "build oracle/_ref first (make -C oracle)"

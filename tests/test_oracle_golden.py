@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import assert_bit_equal, golden_field, rel_max
+from conftest import GOLDEN, assert_bit_equal, golden_field, rel_max
 from oracle import oracle as O
 
 
@@ -225,3 +225,24 @@ def test_image_laplacian_known_answer_bit_exact():
             img.tofile(os.path.join(td, "dir.image"))
             subprocess.check_call([exe], cwd=td)
             assert_bit_equal(np.fromfile(os.path.join(td, "dir.imalap"), np.float32).reshape(151, 151), want, "fresh run of the reference program")
+
+
+def test_image_compare_restatement_reproduces_the_reference_tool_output():
+    """orc_image_compare against the stdout of the reference's own psnr binary (tests/golden/psnr_reference_output.json, written by
+    make_golden.py from runs of models/marmousi/psnr): the same printed lines, character for character, and the same dir.output."""
+    import hashlib
+    import json
+    g = json.load(open(os.path.join(GOLDEN, "psnr_reference_output.json")))
+    img = golden_field("dd_3lay_mod_dir_image.f32", (151 * 151,))
+    files = {"dd_3lay_mod_dir_image.f32": img, "dd_3lay_mod_dir_imalap.f32": golden_field("dd_3lay_mod_dir_imalap.f32", (151 * 151,)),
+             "noisy.f32": (img + np.float32(0.05) * np.abs(img).max() * np.random.default_rng(7).standard_normal(img.size).astype(np.float32)).astype(np.float32)}
+    n = 0
+    for c in g["cases"]:
+        if "a" not in c:
+            continue
+        with np.errstate(divide="ignore", invalid="ignore"):
+            st, diff = O.image_compare(files[c["a"]], files[c["b"]], want_diff=True)
+        assert O.psnr_lines(st) == c["stdout"], (c["a"], c["b"])
+        assert hashlib.sha256(diff.tobytes()).hexdigest() == c["dir_output_sha256"]
+        n += 1
+    assert n == 4

@@ -74,7 +74,7 @@ def test_deck_reader_details(tmp_path):
 
 
 def test_programs_are_built_and_refuse_bad_usage():
-    for exe in ("stencil_code", "rtm_code", "mod_main", "rtm_main"):   # lapfilt has defaults for everything: no usage error to test
+    for exe in ("stencil_code", "rtm_code", "mod_main", "rtm_main"):   # lapfilt has defaults for everything, psnr exits 0 like the reference tool
         path = os.path.join(BIN, exe)
         assert os.access(path, os.X_OK), f"{path} missing: run `make -C parallel_finite_difference_computation_amd/csrc`"
         assert subprocess.run([path], capture_output=True).returncode != 0
@@ -171,6 +171,31 @@ def test_rtm_code_program_vs_oracle_pipeline(tmp_path, with_vel_ext):
     assert len(lines) == ns * (1 + nx * nz) and lines[0] == "======== 0 ========" and lines[1 + nx * nz] == "======== 1 ========"
     last = np.array([float(x) for x in lines[-nx * nz:]], np.float32).reshape(nz, nx).T   # iz outer, ix inner
     assert np.allclose(last, img, rtol=1e-5, atol=1e-5 * np.abs(img).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_vel_ext", [False, True])
+def test_rtm_code_slab_mode_matches_the_serial_program(tmp_path, with_vel_ext):
+    """`rtm_code` with every shot decomposed over 3 ranks (deck key slabs=3 / FDW_SLABS; host threads driving fdw_slabs_shot, here all on
+    this box's one GPU through the in-process communicator, FDW_SLABS_LOCAL=1): dir.image, image.num and dir.image_lap are the serial
+    program's byte for byte, for the random-border and the vel_ext_file deck."""
+    a, b = tmp_path / "serial", tmp_path / "slabs"
+    a.mkdir()
+    nx, nz, *_ = _small_rtm_case(a, with_vel_ext, ns=3, ds=14)
+    shutil.copytree(a, b)
+    r = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=a, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    (b / "input.dat").write_text((b / "input.dat").read_text() + "slabs=3\n")
+    r2 = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=b, capture_output=True, text=True, env=dict(os.environ, FDW_SLABS_LOCAL="1"))
+    assert r2.returncode == 0, r2.stderr + r2.stdout
+    img = (a / "output" / "dir.image").read_bytes()
+    assert len(img) == 4 * nx * nz and np.frombuffer(img, np.float32).any()
+    assert (b / "output" / "dir.image").read_bytes() == img
+    assert (b / "image.num").read_bytes() == (a / "image.num").read_bytes()
+    assert r2.stdout.replace("\r", "").splitlines()[:-1] == r.stdout.replace("\r", "").splitlines()[:-1]          # all but the "> Exec time" line
+    # FDW_GPUS=1 (shots dealt to GPUs) is the plain program
+    r3 = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=a, capture_output=True, text=True, env=dict(os.environ, FDW_GPUS="1"))
+    assert r3.returncode == 0 and (a / "output" / "dir.image").read_bytes() == img
 
 
 @pytest.mark.gpu
@@ -486,3 +511,38 @@ def test_lapfilt_program_reproduces_the_reference_output(tmp_path):
     r = subprocess.run([os.path.join(BIN, "lapfilt")], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "dir.imalap").read_bytes() == open(os.path.join(GOLDEN, "dd_3lay_mod_dir_imalap.f32"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_psnr_program_against_the_reference_tool(tmp_path):
+    """bin/psnr (the reference's offline image comparer models/marmousi/psnr, an ELF without source) against the output of that very binary
+    (tests/golden/psnr_reference_output.json): usage / error messages and exit status identical; ./dir.output (the difference) identical byte
+    for byte; MSE, RMSE, SNR, PSNR printed in its format and equal to 1e-5 -- the tool adds its squares one after the other into fp32 sums,
+    the GPU reduction carries the same terms in double, which shows in the 6th-7th digit -- and F.image_compare equal to the oracle's
+    restatement of the tool (which reproduces its printed digits exactly) to the same tolerance."""
+    import hashlib
+    import json
+    g = json.load(open(os.path.join(GOLDEN, "psnr_reference_output.json")))
+    img = golden_field("dd_3lay_mod_dir_image.f32", (151 * 151,))
+    noisy = (img + np.float32(0.05) * np.abs(img).max() * np.random.default_rng(7).standard_normal(img.size).astype(np.float32)).astype(np.float32)
+    noisy.tofile(tmp_path / "noisy.f32")
+    path = lambda n: str(tmp_path / n) if n in ("noisy.f32", "nonexistent") else os.path.join(GOLDEN, n)
+    exe = os.path.join(BIN, "psnr")
+    for c in g["cases"]:
+        argv = [path(c["a"]), path(c["b"])] if "a" in c else [path(x) for x in c["argv"]]
+        r = subprocess.run([exe] + argv, cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        if "a" not in c:
+            assert r.stdout == c["stdout"], c["argv"]
+            continue
+        assert hashlib.sha256((tmp_path / "dir.output").read_bytes()).hexdigest() == c["dir_output_sha256"]
+        got, want = r.stdout.splitlines(), c["stdout"].splitlines()
+        assert [ln.split()[0] for ln in got] == ["MSE:", "RMSE:", "SNR:", "PSNR:"] and all(len(a) == len(b) for a, b in zip(got, want))
+        for a, b in zip(got, want):
+            va, vb = float(a.split()[1]), float(b.split()[1])
+            assert va == vb or abs(va - vb) <= 1e-5 * abs(vb), (c["a"], c["b"], a, b)
+        st = F.image_compare(np.fromfile(path(c["a"]), np.float32), np.fromfile(path(c["b"]), np.float32))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ost = O.image_compare(np.fromfile(path(c["a"]), np.float32), np.fromfile(path(c["b"]), np.float32))
+        for k, v in zip(("mse", "rmse", "snr", "psnr"), ost):
+            assert st[k] == v or abs(st[k] - v) <= 1e-5 * abs(v), (k, st[k], v)
