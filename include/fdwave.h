@@ -113,6 +113,14 @@ int fdw_shot(fdw_ctx *ctx, const float *v2, int sx, int sz, int gz, const float 
 /* ---- device-array entry points (benchmarks, multi-GPU drivers; asynchronous on `stream`) -------
  * Buffers are caller-owned device memory laid out [nxl][fdw_pitch()] (e.g. a torch tensor).
  *
+ * PRECONDITION of every entry point that takes wavefields (host or device) on a context with compat = 1 and nxe not a multiple of 8:
+ * inside the damped strip (columns < 8*floor(nzb/8)) the rows the reference never time-steps (>= 8*floor(nxe/8)) must be ZERO.  The
+ * reference damps those rows with taperx every step although nothing ever rewrites them (R:94-117 with the grids of R:185-195); the kernels
+ * here damp on load instead of in place (csrc/fdw_device.h, "lazy taper") and cannot reproduce that for rows they never store.  Every call
+ * site of the reference satisfies it (fields start at zero, R:496-497, R:511-514, and snapshots come from such runs).  The host-array entry
+ * points check it and return FDW_EINVAL; the fdw_dev_* ones cannot (the data is on the device) -- a caller that violates it gets values
+ * in those few rows of the strip that differ from the reference's.  A source row in those rows is refused (FDW_EINVAL) by every path.
+ *
  * fdw_dev_step    one fused time step on rows [r0,r1) of the slab:
  *                   mode 0 FWD   taper + Laplacian + leap-frog + point source  (R:264-267)
  *                   mode 1 PLAIN Laplacian + leap-frog                          (R:317-318)

@@ -85,6 +85,7 @@ struct fdw_ctx {
     bool model_resident = false, v2_resident = false;
     // a batch of shots through one launch per time step (fdw_shot_batch): per-shot copies of the eight fields, v2, image, gather
     int nbatch = 1, batch_dsx = 0, batch_cap = 0, batch_nt = 0;
+    bool batch_all = false;      // the batch buffers hold the RTM loop's full set (else: the modelling loop's two fields + gathers)
     float* bfld[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float *b_v2 = nullptr, *b_img = nullptr, *b_dobs = nullptr;
     float* d_raw = nullptr;      // gathers as the caller holds them ([shot][nx][nt]) before the transposition on the device
@@ -1646,24 +1647,37 @@ extern "C" int fdw_shot_batch_max(const fdw_ctx* c)
     return (int)std::max<long>(1, std::min<long>({by_fill, by_mem, 64}));
 }
 
-static int ensure_batch_buffers(fdw_ctx* c, int n)
+// Per-shot copies of what a batch needs: the RTM loop (need_all) its eight fields, v2, image and gathers; the modelling loop only two
+// fields and the gathers.  On an allocation failure whatever was allocated is released again (the callers then run the shots one by one).
+static int ensure_batch_buffers(fdw_ctx* c, int n, bool need_all)
 {
     const size_t nx = c->nx, nt = std::max(c->prm.nt, 1);
-    if (c->batch_cap >= n) return FDW_OK;
+    if (c->batch_cap >= n && (c->batch_all || !need_all)) return FDW_OK;
     float** all[] = {&c->bfld[0], &c->bfld[1], &c->bfld[2], &c->bfld[3], &c->bfld[4], &c->bfld[5], &c->bfld[6], &c->bfld[7], &c->b_v2, &c->b_img, &c->b_dobs};
+    auto release = [&] {
+        for (float** q : all) {
+            if (*q) (void)hipFree(*q);
+            *q = nullptr;
+        }
+        c->batch_cap = 0;
+        c->batch_all = false;
+    };
+    release();
     for (float** q : all) {
-        if (*q) (void)hipFree(*q);
-        *q = nullptr;
-    }
-    c->batch_cap = 0;
-    for (float** q : all) {
+        const bool wanted = need_all || q == &c->bfld[0] || q == &c->bfld[1] || q == &c->b_dobs;
+        if (!wanted) continue;
         const size_t elems = (q == &c->b_dobs ? nx * nt : field_elems(c)) * (size_t)n;
         hipError_t e = hipMalloc((void**)q, elems * sizeof(float));
-        if (e != hipSuccess) return fail(FDW_ENOMEM, "hipMalloc(%zu bytes) failed: %s", elems * sizeof(float), hipGetErrorString(e));
-        HIP_TRY(hipMemset(*q, 0, elems * sizeof(float)));
+        if (e == hipSuccess) e = hipMemset(*q, 0, elems * sizeof(float));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            release();
+            return fail(FDW_ENOMEM, "batch of %d shots: hipMalloc / hipMemset(%zu bytes) failed: %s", n, elems * sizeof(float), hipGetErrorString(e));
+        }
     }
     HIP_TRY(hipDeviceSynchronize());
     c->batch_cap = n;
+    c->batch_all = need_all;
     return FDW_OK;
 }
 
@@ -1705,7 +1719,16 @@ extern "C" int fdw_shot_batch(fdw_ctx* c, int nshots, const float* v2_all, unsig
         }
         return FDW_OK;
     }
-    if ((rc = ensure_work_buffers(c, 8, true)) || (rc = ensure_batch_buffers(c, nshots)) || (rc = upload_source(c, srce, nt))) return rc;
+    if ((rc = ensure_work_buffers(c, 8, true))) return rc;
+    if ((rc = ensure_batch_buffers(c, nshots, true)) == FDW_ENOMEM) {          // no room for the batch: the shots one after the other
+        for (int b = 0; b < nshots; b++) {
+            if (!v2_all && (rc = fdw_dev_extendvel_linear(c, draw_offset + (unsigned long long)b * fdw_border_draws(c->nx, c->nz, c->prm.nxb, c->prm.nzb), nullptr)))
+                return rc;
+            if ((rc = shot_impl(c, v2_all ? v2_all + b * ne : nullptr, sx0 + b * dsx, sz, gz, srce, d_obs + b * ng, imloc + b * ni, nullptr, nullptr))) return rc;
+        }
+        return FDW_OK;
+    }
+    if (rc || (rc = upload_source(c, srce, nt))) return rc;
     hipStream_t s = c->stream;
     if ((rc = gathers_to_device(c, d_obs, c->b_dobs, nshots))) return rc;      // [shot][nx][nt] -> [shot][nt][nx]
     const long long draws = fdw_border_draws(c->nx, c->nz, c->prm.nxb, c->prm.nzb);
@@ -1769,7 +1792,13 @@ extern "C" int fdw_model_shot_batch(fdw_ctx* c, int nshots, const float* vel2, i
         return FDW_OK;
     }
     HIP_TRY(hipSetDevice(c->device));
-    if ((rc = ensure_work_buffers(c, 2, false)) || (rc = ensure_batch_buffers(c, nshots)) || (rc = upload_source(c, srce, nt))) return rc;
+    if ((rc = ensure_work_buffers(c, 2, false))) return rc;
+    if ((rc = ensure_batch_buffers(c, nshots, false)) == FDW_ENOMEM) {         // no room for the batch: the shots one after the other
+        for (int b = 0; b < nshots; b++)
+            if ((rc = fdw_model_shot(c, vel2, sx0 + b * dsx, sz, gz, srce, nt, data + b * ng))) return rc;
+        return FDW_OK;
+    }
+    if (rc || (rc = upload_source(c, srce, nt))) return rc;
     if ((rc = ensure_cap(&c->d_raw, &c->raw_cap, ng * nshots))) return rc;
     hipStream_t s = c->stream;
     if ((rc = upload_rows(c, c->d_v2, vel2, s))) return rc;

@@ -90,11 +90,11 @@ def run(deck_path, out=sys.stdout):
     vel_ext = np.memmap(d["vel_ext_file"], np.float32, "r", shape=(ns, nxe, nze)) if d["vel_ext_file"] else None
     vpe = np.zeros((nxe, nze), np.float32)
     vpe[nxb:nxb + nx, nzb:nzb + nz] = vp
-    # a shot of a small deck fills a few percent of one GPU: this rank's shots go through up to FDW_SHOT_WORKERS (default 2) contexts
+    # a shot of a small deck fills a few percent of one GPU: this rank's shots go through up to FDW_SHOT_WORKERS (default 4, as in rtm_code) contexts
     # (own stream and buffers each) on host threads; ctypes releases the GIL inside the library
     import concurrent.futures
     import threading
-    nworkers = max(1, int(os.environ.get("FDW_SHOT_WORKERS", "2")))
+    nworkers = max(1, int(os.environ.get("FDW_SHOT_WORKERS", "4")))
     local_ctx = threading.local()
 
     dev_border = vel_ext is None and "FDW_HOST_BORDER" not in os.environ and nxb != 1 and nzb != 1 and nzb <= nxe
@@ -117,6 +117,8 @@ def run(deck_path, out=sys.stdout):
     if (dev_border or vel_ext is not None) and "FDW_NO_SHOT_BATCH" not in os.environ:
         ctx = api.FDWave(d["order"], nxe, nze, nxb, nzb, nt, d["fac"], d["dx"], d["dz"], d["dt"], compat=True, device=local)
         B = ctx.shot_batch_max()
+        if B <= 1:
+            ctx.close()        # the probing context is not needed: the per-thread contexts below do the work
         if B > 1:
             batched = True
             if dev_border:
@@ -147,10 +149,12 @@ def run(deck_path, out=sys.stdout):
             mine[s] = im
     # stack in shot order on rank 0 (fd-code.cu:522-528)
     if world > 1:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
+        # only rank 0 stacks: the images travel to it alone (ns x nx x nz floats through the host; a sum-reduction would reorder the
+        # fp32 additions and break the byte identity with the serial program)
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(mine, gathered, dst=0)
         allimg = {}
-        for g in gathered:
+        for g in gathered or ():
             allimg.update(g)
     else:
         allimg = mine
