@@ -226,10 +226,12 @@ int fdw_rtm_stored_shot(fdw_ctx *ctx, const float *vel2, int sx, int sz, int gz,
 int fdw_image_laplacian(int device, const float *img, int nx, int nz, float dx, float dz, float *out);
 /* fdw_image_compare  the reference's image comparer models/marmousi/psnr ("./psnr file1 file2"; it ships as an ELF without source, so its
  *                 behaviour is restated from its output): stats = {MSE = mean (a-b)^2, RMSE, SNR = 10 log10(sum b^2 / sum (a-b)^2) dB,
- *                 PSNR = 20 log10(max |b| / RMSE) dB}; diff (may be NULL) = a - b, what the tool writes to ./dir.output.  Reduction on
- *                 `device`: the fp32 squares summed in double, whereas the tool adds them one after the other in fp32 -- its printed values
- *                 carry that rounding in the 6th-7th digit. */
-int fdw_image_compare(int device, const float *a, const float *b, size_t n, float *diff, double stats[4]);
+ *                 PSNR = 20 log10(max |b| / RMSE) dB}; diff (may be NULL) = a - b, what the tool writes to ./dir.output.  On `device`.
+ *                 exact_sums = 0: the tool's own arithmetic -- the squares added one after the other into fp32 sums (a serial recurrence: one
+ *                 lane walks the arrays, ~10 ns per element), fp32 quotient and root -- so the values are the tool's, digit for digit;
+ *                 exact_sums = 1: a parallel reduction carrying the same terms in double (fast; differs from the tool's figures by the
+ *                 rounding the tool accumulates, up to a few 1e-5 relative on the reference's own images). */
+int fdw_image_compare(int device, const float *a, const float *b, size_t n, float *diff, double stats[4], int exact_sums);
 
 /* host <-> pitched device copies (dense [rows][nze] on the host side), synchronous */
 int fdw_upload_field(fdw_ctx *ctx, float *d_dst, const float *h_src);

@@ -56,7 +56,7 @@ SIGNATURES = [
     ("fdw_dev_taper_finalize", C.c_int, [vp, vp, vp]),
     ("fdw_model_shot", C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p]),
     ("fdw_image_laplacian", C.c_int, [C.c_int, f32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p]),
-    ("fdw_image_compare", C.c_int, [C.c_int, f32p, f32p, C.c_size_t, vp, C.POINTER(C.c_double)]),
+    ("fdw_image_compare", C.c_int, [C.c_int, f32p, f32p, C.c_size_t, vp, C.POINTER(C.c_double), C.c_int]),
     ("fdw_rtm_stored_shot", C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_size_t, C.c_int, f32p]),
     ("fdw_border_draws", C.c_longlong, [C.c_int] * 4),
     ("fdw_model_resident", C.c_int, [vp, f32p]),

@@ -83,14 +83,15 @@ def image_laplacian(img, dx, dz, device=0):
     return out
 
 
-def image_compare(a, b, device=0, want_diff=False):
-    """The reference's `./psnr file1 file2` (models/marmousi/psnr) on the GPU: dict(mse, rmse, snr, psnr) and, if asked, the difference a - b."""
+def image_compare(a, b, device=0, want_diff=False, exact_sums=False):
+    """The reference's `./psnr file1 file2` (models/marmousi/psnr) on the GPU: dict(mse, rmse, snr, psnr) and, if asked, the difference a - b.
+    exact_sums=False: the tool's own (serial fp32) sums, its figures digit for digit; True: a parallel reduction in double."""
     a, b = np.ascontiguousarray(a, np.float32).ravel(), np.ascontiguousarray(b, np.float32).ravel()
     if a.size != b.size:
         raise ValueError("sizes differ")
     st = (C.c_double * 4)()
     diff = np.zeros_like(a) if want_diff else None
-    check(lib().fdw_image_compare(device, a, b, a.size, diff.ctypes.data if want_diff else None, st))
+    check(lib().fdw_image_compare(device, a, b, a.size, diff.ctypes.data if want_diff else None, st, int(exact_sums)))
     out = dict(mse=st[0], rmse=st[1], snr=st[2], psnr=st[3])
     return (out, diff) if want_diff else out
 

@@ -116,8 +116,9 @@ hipError_t launch_selftest(const float* src, float* out, hipStream_t s);
 hipError_t launch_static_rows(float* pp, const float* psrc, float* img, const float* samples, int pitch, int row0, int nrows, int gz,
                               int img_z0, int img_z1, hipStream_t s);
 hipError_t launch_image_laplacian(const float* d_img, float* d_out, int nx, int nz, float dx, float dz, hipStream_t s);
-// d_part: 3 * nblocks doubles of scratch; d_out: {sum (a-b)^2, sum b^2, max |b|}
-hipError_t launch_image_compare(const float* a, const float* b, size_t n, float* diff, double* d_part, int nblocks, double* d_out, hipStream_t s);
+// d_part: 3 * nblocks doubles of scratch; d_out: {sum (a-b)^2, sum b^2, max |b|} carried in double and, with `serial`, [3], [4] = the two
+// sums as the reference tool forms them (one term after the other into fp32 sums)
+hipError_t launch_image_compare(const float* a, const float* b, size_t n, float* diff, double* d_part, int nblocks, double* d_out, int serial, hipStream_t s);
 
 // ---- random-border velocity model on the device (fdw_border.hip) ----
 constexpr int kRandLag = 31;          // glibc TYPE_3: y[t] = y[t-31] + y[t-3]

@@ -608,10 +608,26 @@ __global__ __launch_bounds__(256) void fdw_image_compare_final_kernel(const doub
     }
     if (threadIdx.x == 0) { out[0] = sh[0][0]; out[1] = sh[1][0]; out[2] = sh[2][0]; }
 }
-hipError_t launch_image_compare(const float* a, const float* b, size_t n, float* diff, double* d_part, int nblocks, double* d_out, hipStream_t s)
+// The tool's own arithmetic: the squares (formed in double) added one after the other into fp32 sums -- a serial recurrence, so ONE lane walks
+// the arrays (an offline tool: ~10 ns per element).  out[3] = sum (a-b)^2, out[4] = sum b^2 as the tool holds them.
+__global__ void fdw_image_compare_serial_kernel(const float* a, const float* b, size_t n, double* out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float sd = 0.0f, sb = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        const float y = b[i];
+        const float d = a[i] - y;
+        sd = (float)((double)sd + (double)d * (double)d);
+        sb = (float)((double)sb + (double)y * (double)y);
+    }
+    out[3] = (double)sd;
+    out[4] = (double)sb;
+}
+hipError_t launch_image_compare(const float* a, const float* b, size_t n, float* diff, double* d_part, int nblocks, double* d_out, int serial, hipStream_t s)
 {
     hipLaunchKernelGGL(fdw_image_compare_kernel, dim3(nblocks), dim3(256), 0, s, a, b, n, diff, d_part);
     hipLaunchKernelGGL(fdw_image_compare_final_kernel, dim3(1), dim3(256), 0, s, d_part, nblocks, d_out);
+    if (serial) hipLaunchKernelGGL(fdw_image_compare_serial_kernel, dim3(1), dim3(64), 0, s, a, b, n, d_out);
     return hipGetLastError();
 }
 

@@ -1,8 +1,9 @@
 /* psnr -- drop-in for the reference's image comparer cuda_reference_RTM/models/marmousi/psnr (an ELF without source; SURVEY.md section 4:
  * "Usage: ./psnr file1 file2", prints MSE / RMSE / SNR / PSNR).  Behaviour restated from the tool's own output: two raw fp32 files of equal
  * size; MSE = mean (f1-f2)^2, RMSE, SNR = 10 log10(sum f2^2 / sum (f1-f2)^2), PSNR = 20 log10(max |f2| / RMSE), each printed as
- * "%-10s %15e"; the difference f1 - f2 is written to ./dir.output; the messages and the exit status (always 0) are the tool's.  The sums
- * are formed on the GPU (fdw_image_compare). */
+ * "%-10s %15e"; the difference f1 - f2 is written to ./dir.output; the messages and the exit status (always 0) are the tool's.  Everything
+ * is computed on the GPU (fdw_image_compare), in the tool's own arithmetic, so the printed figures are the tool's digit for digit
+ * (FDW_PSNR_EXACT_SUMS=1: a parallel reduction in double instead). */
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -41,7 +42,7 @@ int main(int argc, char **argv)
     fclose(f1);
     fclose(f2);
     double st[4];
-    if (fdw_image_compare(0, a, b, n, d, st) != FDW_OK) {
+    if (fdw_image_compare(0, a, b, n, d, st, getenv("FDW_PSNR_EXACT_SUMS") != NULL) != FDW_OK) {      /* default: the tool's own serial fp32 sums */
         fprintf(stderr, "psnr: %s\n", fdw_last_error());
         return EXIT_FAILURE;
     }

@@ -516,10 +516,10 @@ def test_lapfilt_program_reproduces_the_reference_output(tmp_path):
 @pytest.mark.gpu
 def test_psnr_program_against_the_reference_tool(tmp_path):
     """bin/psnr (the reference's offline image comparer models/marmousi/psnr, an ELF without source) against the output of that very binary
-    (tests/golden/psnr_reference_output.json): usage / error messages and exit status identical; ./dir.output (the difference) identical byte
-    for byte; MSE, RMSE, SNR, PSNR printed in its format and equal to 1e-5 -- the tool adds its squares one after the other into fp32 sums,
-    the GPU reduction carries the same terms in double, which shows in the 6th-7th digit -- and F.image_compare equal to the oracle's
-    restatement of the tool (which reproduces its printed digits exactly) to the same tolerance."""
+    (tests/golden/psnr_reference_output.json): stdout identical character for character -- usage / error messages, and the MSE, RMSE, SNR,
+    PSNR lines, whose serial fp32 sums one GPU lane reproduces -- exit status identical, ./dir.output (the difference) identical byte for
+    byte; the parallel reduction in double (exact_sums) agrees with the oracle's restatement to 1e-4 (the tool's own accumulated rounding
+    reaches 3e-5 on these images)."""
     import hashlib
     import json
     g = json.load(open(os.path.join(GOLDEN, "psnr_reference_output.json")))
@@ -536,13 +536,11 @@ def test_psnr_program_against_the_reference_tool(tmp_path):
             assert r.stdout == c["stdout"], c["argv"]
             continue
         assert hashlib.sha256((tmp_path / "dir.output").read_bytes()).hexdigest() == c["dir_output_sha256"]
-        got, want = r.stdout.splitlines(), c["stdout"].splitlines()
-        assert [ln.split()[0] for ln in got] == ["MSE:", "RMSE:", "SNR:", "PSNR:"] and all(len(a) == len(b) for a, b in zip(got, want))
-        for a, b in zip(got, want):
-            va, vb = float(a.split()[1]), float(b.split()[1])
-            assert va == vb or abs(va - vb) <= 1e-5 * abs(vb), (c["a"], c["b"], a, b)
-        st = F.image_compare(np.fromfile(path(c["a"]), np.float32), np.fromfile(path(c["b"]), np.float32))
+        assert r.stdout == c["stdout"], (c["a"], c["b"])
+        fa, fb = np.fromfile(path(c["a"]), np.float32), np.fromfile(path(c["b"]), np.float32)
         with np.errstate(divide="ignore", invalid="ignore"):
-            ost = O.image_compare(np.fromfile(path(c["a"]), np.float32), np.fromfile(path(c["b"]), np.float32))
+            ost = O.image_compare(fa, fb)
+        st, st2 = F.image_compare(fa, fb), F.image_compare(fa, fb, exact_sums=True)
         for k, v in zip(("mse", "rmse", "snr", "psnr"), ost):
-            assert st[k] == v or abs(st[k] - v) <= 1e-5 * abs(v), (k, st[k], v)
+            assert st[k] == v, (k, st[k], v)
+            assert st2[k] == v or abs(st2[k] - v) <= 1e-4 * max(abs(v), 1.0), (k, st2[k], v)
