@@ -104,7 +104,10 @@ hipError_t launch_step2(const Step2Args& a, int half_order, int mode, hipStream_
 // kPipeSteps time steps per pass (wave pipeline through LDS, order 8, FWD / PLAIN): see fdw_stepn_kernel.  Uses Step2Args with
 // out1 = u^{n+kPipeSteps-1}, out2 = u^{n+kPipeSteps}, inj -> kPipeSteps source samples, nstrip = strips of 64-2*kPipeSteps cells,
 // nblk = nstrip * chunks workgroups of kPipeSteps waves.
-constexpr int kPipeSteps = 4;
+#ifndef FDW_PIPE_STEPS
+#define FDW_PIPE_STEPS 4      // experiments: 2 = a pipeline of two waves (build_variants.sh)
+#endif
+constexpr int kPipeSteps = FDW_PIPE_STEPS;
 hipError_t launch_stepn(const Step2Args& a, int half_order, int mode, hipStream_t s);
 
 hipError_t launch_step_fast(const StepArgs& a, int half_order, int mode, int prefetch, hipStream_t s);

@@ -33,7 +33,7 @@ namespace fdw {
 #define FDW_PIPE_ROWS 1    // march steps between two workgroup barriers of the pipeline kernel (1 or 2)
 #endif
 // v2 FIFO depth: the last wave reads row m - (NS-1)(H+ROWS) while wave 0 writes rows m .. m+ROWS-1
-constexpr int pipe_fifo_rows(int ns, int h, int rows) { return rows == 1 ? 16 : (ns - 1) * (h + rows) + rows; }
+constexpr int pipe_fifo_rows(int ns, int h, int rows) { return rows == 1 ? ((ns - 1) * (h + 1) + 1 <= 8 ? 8 : 16) : (ns - 1) * (h + rows) + rows; }
 template <int FD>
 __device__ __forceinline__ int pipe_fifo_slot(int m)
 {

@@ -16,12 +16,14 @@ def timeit(fn, n=12, warm=3):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 cases = [((8192, 8192), (173, 123)), ((1152, 8192), (43, 33, 63)), ((4096, 4096), (83,)), ((16384, 16384), (253,))]
+if os.environ.get("PIPE_CHUNKS"):
+    cases = [(c[0], tuple(int(x) for x in os.environ["PIPE_CHUNKS"].split(","))) for c in cases]
 if len(sys.argv) > 1:
     cases = [c for c in cases if str(c[0][0]) in sys.argv[1:]]
 for (nx, nz), chunks in cases:
     for xchunk in chunks:
         ctx = F.FDWave(8, nx, nz, 64, 64, 100, 0.75, 10.0, 10.0, 0.001, compat=False)
-        ctx.set_tuning(xchunk=xchunk, two_step=4)
+        ctx.set_tuning(xchunk=xchunk, two_step=int(os.environ.get("PIPE_MODE", "4")))
         bufs = [torch.randn((nx, ctx.pitch), device=dev) * 1e-3 for _ in range(4)]
         for b in bufs:
             b[:, nz:] = 0
