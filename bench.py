@@ -562,13 +562,40 @@ def main():
     srce = torch.from_numpy(F.ricker_wavelet(nt, DT, FPEAK)).to(dev)
     sx, sz = n // 2, n // 2
     c_driver = (world > 1 and args.backend == "nccl") or os.environ.get("FDW_FORCE_SLAB_DRIVER") == "c"      # the latter: the multi-GPU code path on one rank (tests)
-    slabs = comm = None
+    slabs = comm = harness_group = None
     use_pipe = False
     if c_driver:
-        uid = [F.Comm.unique_id() if rank == 0 else None]
+        # the communicator: ncclGetUniqueId on rank 0, the bytes to every rank through the control-plane group, ncclCommInitRank (one rank per GPU),
+        # and one message to the own rank as a check.  Should librccl not be usable from the C library on this machine, every rank falls back
+        # -- together -- to the Python harness over torch.distributed's own RCCL group rather than lose the measurement.
+        err = None
+        uid = [None]
+        if rank == 0:
+            try:
+                uid = [F.Comm.unique_id()]
+            except F.FdwError as e:
+                err = e
         if world > 1:
             dist.broadcast_object_list(uid, src=0)
-        comm = F.Comm.rccl(uid[0], rank, world, local_rank)                  # ncclCommInitRank: one rank per GPU
+        if uid[0] is not None:
+            try:
+                comm = F.Comm.rccl(uid[0], rank, world, local_rank)
+                comm.selftest()
+            except F.FdwError as e:
+                err = e
+        else:
+            err = err or RuntimeError("rank 0 could not create the RCCL unique id")
+        bad = torch.tensor([1.0 if err is not None else 0.0])
+        if world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if bad.item() > 0:
+            print(f"[bench] rank {rank}: RCCL inside libfdwave.so is not usable here ({err}); falling back to the torch.distributed harness", file=sys.stderr, flush=True)
+            if comm is not None:
+                comm.close()
+            comm, c_driver = None, False
+            if world > 1:
+                harness_group = dist.new_group(backend="nccl")
+    if c_driver:
         if args.pipe != "auto":
             os.environ["FDW_SLAB_PIPE"] = "1" if args.pipe == "on" else "0"
         if args.no_overlap:
@@ -679,7 +706,7 @@ def main():
         newest = fields[roles["ipp"]][geom.g_lo:geom.nxl - geom.g_hi]
     else:
         fields = slab_noise_fields(4 if use_pipe else 2)
-        fw = SlabForward(geom, HipSlabStepper(ctx), fields, v2, srce, sx, sz, overlap=not args.no_overlap, pipe_ctx=ctx if use_pipe else None)
+        fw = SlabForward(geom, HipSlabStepper(ctx), fields, v2, srce, sx, sz, group=harness_group, overlap=not args.no_overlap, pipe_ctx=ctx if use_pipe else None)
         torch.cuda.synchronize()       # fields were filled on torch's default stream; the driver's streams do not wait for it
         fw.run(W)
         fw.synchronize()       # also forces torch's lazy creation of both streams outside the timed region
@@ -704,7 +731,7 @@ def main():
         finite = bool(f.item() > 0.5)
 
     check = None
-    if world > 1 and (args.check or (c_driver and not args.no_check)):
+    if world > 1 and (args.check or (args.backend == "nccl" and not args.no_check)):
         # the decomposed field against a single-domain run of the same step sequence (warm-up, then `nwin` windows that replay the
         # source samples W .. W+K-1) on rank 0, bitwise: a halo that arrives late or not at all cannot hide behind a plausible number
         own = newest[:, :n].contiguous().cpu()
@@ -755,7 +782,8 @@ def main():
         }
         if world > 1:
             out["halo_exchange"] = ("RCCL ncclSend/ncclRecv groups issued by libfdwave.so on the communication stream" if c_driver
-                                    else f"torch.distributed {args.backend} (single-GPU rehearsal harness)")
+                                    else ("torch.distributed nccl P2P (fallback harness: RCCL was not usable from libfdwave.so)" if harness_group is not None
+                                          else f"torch.distributed {args.backend} (single-GPU rehearsal harness)"))
             out["decomposition_check"] = check
         out["timing"] = {"windows": nwin, "window_steps": K, "statistic": "median window (each bracketed by barrier + synchronize, max over ranks)",
                          "measured_seconds_min": MIN_TIMED_SECONDS}
