@@ -92,6 +92,7 @@ struct fdw_ctx {
     size_t raw_cap = 0;
     int no_fused_back = 0;   // experiments / tests: backward iterations as two launches (source step, receiver step) -- FDW_NO_FUSED_BACK=1
     int no_back_pipe = 0;    // experiments / tests: no wave-pipeline passes in the backward loop -- FDW_NO_BACK_PIPE=1
+    int no_back_fused = 0;   // experiments / tests: the backward pipeline as two passes (source field, receiver field) instead of the fused kernel -- FDW_NO_BACK_FUSED=1
 };
 
 static size_t field_elems(const fdw_ctx* c) { return (size_t)c->nxl * (size_t)c->pitch; }
@@ -198,6 +199,7 @@ extern "C" int fdw_create_slab(const fdw_params* prm, const fdw_slab* slab, int 
     c->pitch = ((prm->nze + 63) / 64) * 64;  // 256-B aligned rows: every lane's float4 is aligned
     if (const char* nf = getenv("FDW_NO_FUSED_BACK")) c->no_fused_back = atoi(nf);
     if (const char* nf = getenv("FDW_NO_BACK_PIPE")) c->no_back_pipe = atoi(nf);
+    if (const char* nf = getenv("FDW_NO_BACK_FUSED")) c->no_back_fused = atoi(nf);
     if (const char* pad = getenv("FDW_PITCH_PAD")) {   // experiment knob: extra floats per row (multiple of 4)
         const int extra = atoi(pad);
         if (extra > 0 && extra % 4 == 0) c->pitch += extra;
@@ -610,11 +612,13 @@ static bool pipe_pays(const fdw_ctx* c)
 
 // FWD: d_inj -> kPipeSteps source samples srce[it .. it+kPipeSteps-1]; PLAIN: no taper, no injection.
 // d_out1 = u^{n+kPipeSteps-1}, d_out2 = u^{n+kPipeSteps}.
-struct StepnBack {      // the two passes of the backward loop (Step2Args: lvl0, lvl1, plev, img, inj_stride)
+struct StepnBack {      // the passes of the backward loop (Step2Args: lvl0, lvl1, plev, img, inj_stride, rp ...)
     float *lvl0 = nullptr, *lvl1 = nullptr;       // PLAIN_ALL: where waves 0 and 1 store their levels
     const float* plev[kPipeSteps] = {};           // RECV: the source field of iterations it .. it+3
     float* img = nullptr;
-    int inj_stride = 0;                           // RECV: floats between the sample rows of consecutive iterations
+    int inj_stride = 0;                           // RECV, BACK4: floats between the sample rows of consecutive iterations
+    const float *rp = nullptr, *rpp = nullptr;    // BACK4: the receiver pair (the positional arguments are the source field's)
+    float *rout1 = nullptr, *rout2 = nullptr;
 };
 struct RowRanges {      // rows the pass produces: [r0, r1) and optionally [r0b, r1b); r1 < 0 = all rows the reference time-steps
     int r0 = 0, r1 = -1, r0b = 0, r1b = 0, xchunk = 0;
@@ -624,8 +628,15 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
                       int rec_z = 0, const StepnBack* bk = nullptr)
 {
     if (c->h != kMaxFastHalfOrder) return fail(FDW_EINVAL, "stepn: the pipelined kernel is built for order 8 only");
-    if (mode != FDW_MODE_FWD && mode != FDW_MODE_PLAIN && mode != FDW_MODE_MOD && mode != FDW_MODE_PLAIN_ALL && mode != FDW_MODE_RECV)
-        return fail(FDW_EINVAL, "stepn: FWD, PLAIN, PLAIN_ALL, RECV or MOD only");
+    if (mode != FDW_MODE_FWD && mode != FDW_MODE_PLAIN && mode != FDW_MODE_MOD && mode != FDW_MODE_PLAIN_ALL && mode != FDW_MODE_RECV && mode != FDW_MODE_BACK4)
+        return fail(FDW_EINVAL, "stepn: FWD, PLAIN, PLAIN_ALL, RECV, BACK4 or MOD only");
+    if (mode == FDW_MODE_BACK4) {
+        if (!bk || !bk->img || !d_inj || !bk->rp || !bk->rpp || !bk->rout1 || !bk->rout2) return fail(FDW_EINVAL, "stepn: BACK4 needs the receiver pair, its outputs, samples and image");
+        const float* all[8] = {d_p, d_pp, d_out1, d_out2, bk->rp, bk->rpp, bk->rout1, bk->rout2};
+        for (int i = 0; i < 8; i++)
+            for (int j = i + 1; j < 8; j++)
+                if (all[i] == all[j]) return fail(FDW_EINVAL, "stepn: BACK4 buffers must not alias");
+    }
     if ((mode == FDW_MODE_PLAIN_ALL && (!bk || !bk->lvl0 || !bk->lvl1)) ||
         (mode == FDW_MODE_RECV && (!bk || !bk->img || !d_inj || !bk->plev[0] || !bk->plev[1] || !bk->plev[2] || !bk->plev[3])))
         return fail(FDW_EINVAL, "stepn: the backward passes need their level buffers / source fields, samples and image");
@@ -658,7 +669,10 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
         for (float* o : {d_out1, d_out2}) if (bk->lvl0 == o || bk->lvl1 == o || bk->lvl0 == bk->lvl1 || bk->lvl0 == d_p || bk->lvl0 == d_pp || bk->lvl1 == d_p || bk->lvl1 == d_pp)
             return fail(FDW_EINVAL, "stepn: level buffers must not alias the inputs or outputs");
     }
-    if (mode == FDW_MODE_RECV) {
+    if (mode == FDW_MODE_BACK4) {
+        a.rp = bk->rp; a.rpp = bk->rpp; a.rout1 = bk->rout1; a.rout2 = bk->rout2;
+    }
+    if (mode == FDW_MODE_RECV || mode == FDW_MODE_BACK4) {
         if (inj_z < 0 || inj_z >= c->prm.nze) return fail(FDW_EINVAL, "stepn: receiver depth %d outside the grid", inj_z);
         const int g0 = c->prm.nxb, g1 = c->prm.nxb + std::min(c->nx, c->xlim);       // receivers on interior rows (R:126-129)
         const int l0 = std::max(g0 - c->slab.x_off, 0), l1 = std::min(g1 - c->slab.x_off, c->nxl);
@@ -711,6 +725,10 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
             HIP_TRY(hipMemcpyAsync(bk->lvl0 + off, d_pp + off, n, hipMemcpyDeviceToDevice, s));
             HIP_TRY(hipMemcpyAsync(bk->lvl1 + off, d_p + off, n, hipMemcpyDeviceToDevice, s));
         }
+        if (mode == FDW_MODE_BACK4) {          // and so do the receiver field's
+            HIP_TRY(hipMemcpyAsync(bk->rout1 + off, bk->rpp + off, n, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(bk->rout2 + off, bk->rp + off, n, hipMemcpyDeviceToDevice, s));
+        }
     }
     return FDW_OK;
 }
@@ -727,6 +745,11 @@ extern "C" int fdw_dev_back4(fdw_ctx* c, const float* d_f1, const float* d_f0, f
     hipStream_t s = pick_stream(c, stream);
     RowRanges rr;
     rr.r0 = r0; rr.r1 = r1; rr.r0b = r0b; rr.r1b = r1b; rr.xchunk = xchunk;
+    if (!c->no_back_fused) {      // both fields in one pass of the eight-wave kernel: the levels in between never leave the chip
+        StepnBack b4;
+        b4.rp = d_pr; b4.rpp = d_ppr; b4.rout1 = d_ro1; b4.rout2 = d_ro2; b4.img = d_img; b4.inj_stride = sample_stride;
+        return stepn_impl(c, FDW_MODE_BACK4, d_f1, d_f0, d_v2, d_fo1, d_fo2, pp_twice, d_samples, -1, gz, s, rr, nullptr, 0, &b4);
+    }
     StepnBack fb;
     fb.lvl0 = d_lvl0; fb.lvl1 = d_lvl1;
     int rc = stepn_impl(c, FDW_MODE_PLAIN_ALL, d_f1, d_f0, d_v2, d_fo1, d_fo2, 0, nullptr, -1, 0, s, rr, nullptr, 0, &fb);
@@ -995,7 +1018,7 @@ static int back_loop(fdw_ctx* c, float* const src[4], float* const rcv[4], int g
     // kept: the imaging condition needs each of them), pass 2 advances the receiver field four times, injects each iteration's samples and
     // adds the four products F_{it+j} r^{it+j+1} to the image in iteration order.  Not where receiver rows lie beyond the time-stepped rows.
     const bool pipe = pipe_pays(c) && c->prm.dialect == FDW_DIALECT_RTM && c->nbatch <= 1 && c->prm.nxb + c->nx <= c->upd_x1 && !c->no_back_pipe;
-    if (pipe && nsteps >= 2 + kPipeSteps) {
+    if (pipe && c->no_back_fused && nsteps >= 2 + kPipeSteps) {      // the two-pass form keeps two levels in memory
         if ((rc = alloc_zero(&c->fld[8], field_elems(c))) || (rc = alloc_zero(&c->fld[9], field_elems(c)))) return rc;
     }
     while (it < nsteps) {
@@ -1004,6 +1027,15 @@ static int back_loop(fdw_ctx* c, float* const src[4], float* const rcv[4], int g
             for (int i = 0; i < 4; i++) {
                 if (i != f1 && i != f0) { (o1 < 0 ? o1 : o2) = i; }
                 if (i != rn && i != ro) { (q1 < 0 ? q1 : q2) = i; }
+            }
+            if (!c->no_back_fused) {      // one pass of the eight-wave kernel for both fields
+                StepnBack b4;
+                b4.rp = rcv[rn]; b4.rpp = rcv[ro]; b4.rout1 = rcv[q1]; b4.rout2 = rcv[q2]; b4.img = c->d_img; b4.inj_stride = -(int)nxs;
+                if ((rc = stepn_impl(c, FDW_MODE_BACK4, src[f1], src[f0], c->d_v2, src[o1], src[o2], it > 0, samples(it), -1, gz, c->stream, RowRanges{}, nullptr, 0, &b4))) return rc;
+                f0 = o1; f1 = o2;
+                ro = q1; rn = q2;
+                it += kPipeSteps;
+                continue;
             }
             StepnBack fb;
             fb.lvl0 = c->fld[8]; fb.lvl1 = c->fld[9];

@@ -12,6 +12,7 @@ enum {
     FDW_MODE_MOD = 4,    // forward-modelling step of the CPU-serial sibling (mod_main: fd_step + ptsrc + taper_apply + trace sample)
     FDW_MODE_DD_FWD = 5, // its stored-wavefield RTM, source pass (rtm_main.cpp:165-184: fd_step + one-cell source + taper_apply2)
     FDW_MODE_BACK = 7,   // one whole backward iteration of fd_back in a single pass: source-field step + receiver step + imaging (R:317-329)
+    FDW_MODE_BACK4 = 9,  // wave-pipeline kernel only: four whole iterations of fd_back in one pass of an eight-wave workgroup (source + receiver fields)
     FDW_MODE_PLAIN_ALL = 8, // wave-pipeline kernel only: PLAIN with all four time levels stored (source field of the backward loop)
     FDW_MODE_DD_RECV = 6 // its receiver pass (rtm_main.cpp:197-220) + img += stored source field * CURRENT receiver field (rtm_main.cpp:224-230)
 };
@@ -98,6 +99,9 @@ struct Step2Args {
     float *lvl0, *lvl1;
     const float* plev[kMaxPipeSteps];
     int inj_stride;
+    //   FDW_MODE_BACK4      both in one pass (fdw_back4_kernel): p / pp / out1 / out2 are the source field's, these the receiver field's
+    const float *rp, *rpp;
+    float *rout1, *rout2;
 };
 hipError_t launch_step2(const Step2Args& a, int half_order, int mode, hipStream_t s);
 

@@ -33,6 +33,7 @@ namespace fdw {
 #define FDW_PIPE_ROWS 1    // march steps between two workgroup barriers of the pipeline kernel (1 or 2)
 #endif
 // v2 FIFO depth: the last wave reads row m - (NS-1)(H+ROWS) while wave 0 writes rows m .. m+ROWS-1
+constexpr int kFusedFifoRows = 20;      // fused backward kernel: a v2 row is 1 + 3 (H + 1) = 16 march steps under way from the first wave to the last
 constexpr int pipe_fifo_rows(int ns, int h, int rows) { return rows == 1 ? ((ns - 1) * (h + 1) + 1 <= 8 ? 8 : 16) : (ns - 1) * (h + rows) + rows; }
 template <int FD>
 __device__ __forceinline__ int pipe_fifo_slot(int m)
@@ -42,18 +43,26 @@ __device__ __forceinline__ int pipe_fifo_slot(int m)
 }
 
 // BK: 0 forward / modelling loops; 1 source field of the backward loop (every wave stores its level); 2 receiver field of the backward
-// loop (INJ = 2: trace samples per level, imaging against plev[k], image rows chained through imf)
+// loop (INJ = 2: trace samples per level, imaging against plev[k], image rows chained through imf);
+// 3 / 4: the two roles of the FUSED backward kernel (fdw_back4_kernel: eight waves, four per field): 3 = source field (PLAIN arithmetic,
+// wave 0 fills the shared v2 FIFO, every wave's new row also serves the receiver wave of its level), 4 = receiver field (one march step
+// behind: its rows, windows and FIFO slots are those of role 3 shifted by D = 1, so that the source-field row it images against was
+// written to the link buffers during the step before; v2 for all four waves from the FIFO; image as in BK 2)
 template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0, int ROWS = FDW_PIPE_ROWS>
 __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const int k, const int cs, const int xa, const int xe,
-                                       f4 (*link)[2][2][ROWS][64], f4 (*fifo)[64], f4 (*imf)[64] = nullptr)
+                                       f4 (*link)[2][2][ROWS][64], f4 (*fifo)[64], f4 (*imf)[64] = nullptr, f4 (*linkx)[2][2][ROWS][64] = nullptr)
 {
+    constexpr bool IMG = (BK == 2 || BK == 4);
+    constexpr int D = (BK == 4) ? 1 : 0;                      // this role runs D march steps behind
+    constexpr int DL = (BK >= 3) ? 1 : 0;                     // ... so both roles of the fused kernel loop one step longer
     // ROWS march steps between two workgroup barriers (1 or 2): a wave consumes what its predecessor produced during the previous
     // ROWS steps, so consecutive waves work H + ROWS rows apart and a wave's first good row comes ROWS later per stage.
     constexpr int R = ((2 * H + PF + PF - 1) / PF) * PF;
     constexpr int LOOK = R - 2 * H;
     constexpr int SK = H + ROWS;
-    constexpr int FD = pipe_fifo_rows(NS, H, ROWS);
+    constexpr int FD = BK >= 3 ? kFusedFifoRows : pipe_fifo_rows(NS, H, ROWS);
     static_assert(ROWS == 1 || (ROWS == 2 && R % 2 == 0), "one or two rows per barrier");
+    static_assert(BK < 3 || ROWS == 1, "the fused backward kernel assumes one row per barrier");
     const bool first = (k == 0);
     const int cell = cs + lane;
     const int z0 = cell * 4;
@@ -64,11 +73,13 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
     const unsigned row_bytes = (unsigned)a.pitch * 4u;
     const int rowmax = a.nxl - 1;
     const unsigned arr_bytes = (unsigned)a.nxl * row_bytes;               // < 2 GiB (checked by the host)
-    const __amdgpu_buffer_rsrc_t rs_p = array_rsrc(a.p, arr_bytes), rs_pp = array_rsrc(a.pp, arr_bytes), rs_v2 = array_rsrc(a.v2, arr_bytes);
-    const __amdgpu_buffer_rsrc_t rs_out = array_rsrc((k == NS - 1) ? a.out2 : ((BK == 1 && k < NS - 2) ? (k == 0 ? a.lvl0 : a.lvl1) : a.out1), arr_bytes);
+    const float *gp = BK == 4 ? a.rp : a.p, *gpp = BK == 4 ? a.rpp : a.pp;      // the fused kernel's receiver role has its own pair of fields
+    float *go1 = BK == 4 ? a.rout1 : a.out1, *go2 = BK == 4 ? a.rout2 : a.out2;
+    const __amdgpu_buffer_rsrc_t rs_p = array_rsrc(gp, arr_bytes), rs_pp = array_rsrc(gpp, arr_bytes), rs_v2 = array_rsrc(a.v2, arr_bytes);
+    const __amdgpu_buffer_rsrc_t rs_out = array_rsrc((k == NS - 1) ? go2 : ((BK == 1 && k < NS - 2) ? (k == 0 ? a.lvl0 : a.lvl1) : go1), arr_bytes);
     // BK 2: this wave's source-field level and, for wave 0 / the last wave, the image
-    const __amdgpu_buffer_rsrc_t rs_lev = array_rsrc(BK == 2 ? a.plev[k] : a.p, arr_bytes), rs_img = array_rsrc(BK == 2 ? a.img : a.out1, arr_bytes);
-    const unsigned ioff = (BK == 2 && own) ? voff : kLaneOff;             // imaging: owned lanes only
+    const __amdgpu_buffer_rsrc_t rs_lev = array_rsrc(BK == 2 ? a.plev[k] : gp, arr_bytes), rs_img = array_rsrc(IMG ? a.img : go1, arr_bytes);
+    const unsigned ioff = (IMG && own) ? voff : kLaneOff;                 // imaging: owned lanes only
 
     const bool wave_tap = TAPER && (cs * 4 < a.ztap);
     const bool xtap = wave_tap && ((xa - NS * H < a.xt_lo) || (xe + NS * H > a.xt_hi));
@@ -113,14 +124,14 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
     auto load_pw = [&](__amdgpu_buffer_rsrc_t rs, int row) -> f4 { return f4_load_arr(rs, loff, rowoff(row), (FDW_NT & 1) != 0); };
 
     // rows: wave 0's centre row at march step m is s0 + m (what the global loads follow); this wave's is rk + m
-    const int s0 = xa - (NS - 1) * H, b0 = s0 - H;
+    const int s0 = xa - (NS - 1) * H - D, b0 = s0 - H;
     const int rk = s0 - k * SK;
-    const int M = (xe - xa) + (NS - 1) * (2 * H + ROWS);
+    const int M = (xe - xa) + (NS - 1) * (2 * H + ROWS) + DL;
     const int kp = max(k - 1, 0);
     f4 ring[R];
     f4 qpp[PF], qv2[PF];
-    f4 qlv[BK == 2 ? PF : 1], qim[BK == 2 ? PF : 1];                    // BK 2: this wave's source-field rows and (wave 0) the image rows, PF steps ahead
-    const unsigned imoff = (BK == 2 && first) ? ioff : kLaneOff;          // only wave 0 reads the image
+    f4 qlv[BK == 2 ? PF : 1], qim[IMG ? PF : 1];                        // BK 2: this wave's source-field rows; BK 2, 4: (wave 0) the image rows, PF steps ahead
+    const unsigned imoff = (IMG && first) ? ioff : kLaneOff;              // only wave 0 reads the image
     bool zim[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) zim[e] = (z0 + e >= 0) && (z0 + e < a.img_z1);
@@ -136,11 +147,9 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         if constexpr (j >= -PF) {
             constexpr int mm = j + PF;
             qpp[mm] = load_pw(rs_pp, s0 + mm);
-            qv2[mm] = load_pw(rs_v2, s0 + mm);
-            if constexpr (BK == 2) {
-                qlv[mm] = f4_load_arr(rs_lev, ioff, rowoff(rk + mm), (FDW_NT & 1) != 0);
-                qim[mm] = f4_load_arr(rs_img, imoff, rowoff(rk + mm), (FDW_NT & 1) != 0);
-            }
+            if constexpr (BK != 4) qv2[mm] = load_pw(rs_v2, s0 + mm);
+            if constexpr (BK == 2) qlv[mm] = f4_load_arr(rs_lev, ioff, rowoff(rk + mm), (FDW_NT & 1) != 0);
+            if constexpr (IMG) qim[mm] = f4_load_arr(rs_img, imoff, rowoff(rk + mm), (FDW_NT & 1) != 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -156,7 +165,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
     // [m_lo, m_hi) it keeps the barriers and its memory instructions, which are predicated off through the buffer descriptor so that
     // the s_waitcnt counting stays exact.  That frees a fifth of the issue slots of a 43-row chunk (7 % at 173 rows) for the other
     // workgroups of the CU.
-    const int m_lo = k * (2 * H + ROWS), m_hi = (xe - xa) + 2 * (NS - 1) * H + k * ROWS;
+    const int m_lo = k * (2 * H + ROWS) + D, m_hi = (xe - xa) + 2 * (NS - 1) * H + k * ROWS + D;
     // The frame of the grid (rows / columns where the Laplacian or the update is masked) only concerns the workgroups that touch it;
     // all others take the wave-uniform branch around the mask selects.
     const bool edge = !(FDW_PIPE_OPT & 4) || (cs * 4 < a.lap_z0) || (cs * 4 + 256 > min(a.lap_z1, a.upd_z1)) || (xa - (NS - 1) * H - NS * SK < max(a.lap_x0, 0)) ||
@@ -180,22 +189,26 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             if (wave_tap) taper_row(ring[E], r + H);            // damped once as "p" of this step
         }
         f4 u;
-        float im0, im1, im2, im3;                               // the image row (BK 2), as scalars: defined on every path without an instruction
-        if constexpr (BK == 2) asm volatile("" : "=v"(im0), "=v"(im1), "=v"(im2), "=v"(im3));
+        float im0, im1, im2, im3;                               // the image row (BK 2, 4), as scalars: defined on every path without an instruction
+        if constexpr (IMG) asm volatile("" : "=v"(im0), "=v"(im1), "=v"(im2), "=v"(im3));
         if (act) {
         f4 ppt, v2t;
         if (first) {                                            // wave 0: its rows come from global memory (loaded PF steps ago)
             ppt = qpp[Q];
-            v2t = qv2[Q];
+            if constexpr (BK == 4) {
+                v2t = fifo[pipe_fifo_slot<FD>(m - D)][lane];     // the source-field role's wave 0 parked it one step ago
+            } else {
+                v2t = qv2[Q];
 #if !(FDW_ABL_BITS & 128)
-            fifo[pipe_fifo_slot<FD>(m)][lane] = qv2[Q];
+                fifo[pipe_fifo_slot<FD>(m)][lane] = qv2[Q];
 #endif
+            }
         } else {
 #if FDW_ABL_BITS & 128
             ppt = ring[(U + 1) % R]; v2t = ring[(U + 2) % R];
 #else
             ppt = link[kp][par ^ 1][1][SLOT][lane];
-            v2t = fifo[pipe_fifo_slot<FD>(m - k * SK)][lane];
+            v2t = fifo[pipe_fifo_slot<FD>(m - D - k * SK)][lane];
 #endif
         }
         if (wave_tap) {
@@ -265,15 +278,18 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
                 for (int e = 0; e < 4; ++e) u.v[e] = ihit[e] ? u.v[e] + v : u.v[e];
             }
         }
-        if constexpr (BK == 2) {
+        if constexpr (IMG) {
             // kernel_img (R:133-144) for iteration it + k: img += F_{it+k} * (the receiver field just formed).  The image row enters at wave 0
             // from memory, collects the four products in iteration order on its way through the LDS FIFO and leaves from the last wave.
             f4 im;
             if (first) im = qim[Q];
             else im = imf[r & 15][lane];
             if (r >= xa && r < xe) {
+                f4 lv;
+                if constexpr (BK == 4) lv = linkx[k][par ^ 1][0][SLOT][lane];      // F_{it+k}(r): the source-field wave of this level formed it one step ago
+                else lv = qlv[Q];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) im.v[e] = zim[e] ? im.v[e] + qlv[Q].v[e] * u.v[e] : im.v[e];
+                for (int e = 0; e < 4; ++e) im.v[e] = zim[e] ? im.v[e] + lv.v[e] * u.v[e] : im.v[e];
             }
             if (k < NS - 1) imf[r & 15][lane] = im;
             im0 = im.v[0]; im1 = im.v[1]; im2 = im.v[2]; im3 = im.v[3];
@@ -304,7 +320,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         ring[U] = u;
 #else
         f4_store_arr(rs_out, so, rowoff(r), u);
-        if constexpr (BK == 2) {
+        if constexpr (IMG) {
             const unsigned sim = (k == NS - 1 && act && (r >= xa) && (r < xe)) ? ioff : kLaneOff;
             f4 im;
             im.v[0] = im0; im.v[1] = im1; im.v[2] = im2; im.v[3] = im3;
@@ -313,11 +329,9 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         // ---- look-ahead loads of wave 0 into the slots this step freed ----
         ring[U] = load_p(b0 + m + R);
         qpp[Q] = load_pw(rs_pp, s0 + m + PF);
-        qv2[Q] = load_pw(rs_v2, s0 + m + PF);
-        if constexpr (BK == 2) {
-            qlv[Q] = f4_load_arr(rs_lev, ioff, rowoff(r + PF), (FDW_NT & 1) != 0);
-            qim[Q] = f4_load_arr(rs_img, imoff, rowoff(r + PF), (FDW_NT & 1) != 0);
-        }
+        if constexpr (BK != 4) qv2[Q] = load_pw(rs_v2, s0 + m + PF);
+        if constexpr (BK == 2) qlv[Q] = f4_load_arr(rs_lev, ioff, rowoff(r + PF), (FDW_NT & 1) != 0);
+        if constexpr (IMG) qim[Q] = f4_load_arr(rs_img, imoff, rowoff(r + PF), (FDW_NT & 1) != 0);
 #endif
 #if !(FDW_ABL_BITS & 64)
         if constexpr (SLOT == ROWS - 1) __syncthreads();
@@ -353,6 +367,34 @@ __global__ __launch_bounds__(64 * NS, (FDW_PIPE_ROWS != 1 || BK == 2) ? 3 : (DD 
     }
 }
 
+// Four iterations of the backward loop in ONE pass: a workgroup of eight waves, waves 0-3 the pipeline of the source field (role 3), waves 4-7
+// the pipeline of the receiver field one march step behind (role 4).  The source-field levels never leave the chip: the receiver wave of
+// level k reads F_{it+k}(row) from the link buffer the source-field wave k wrote it to for its own successor.  6 fields in + 5 out per
+// four iterations = 44 B/point (the two-pass form moves 92).  Both roles run the same number of march steps and reach one barrier per step.
+template <int H, int NS, int PF>
+__global__ __launch_bounds__(128 * NS, 2) void fdw_back4_kernel(const Step2Args a)
+{
+    const int lane = threadIdx.x & 63;
+    const int k8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bid = blockIdx.x;
+    const int L = (bid & 7) * a.nper + (bid >> 3);
+    if (L >= a.nblk) return;
+    const int zb = L % a.nstrip;
+    const int xb = L / a.nstrip;
+    const bool second = xb >= a.chunks_a;
+    const int xa = second ? a.r0b + (xb - a.chunks_a) * a.xchunk : a.r0 + xb * a.xchunk;
+    const int xe = min(xa + a.xchunk, second ? a.r1b : a.r1);
+    if (xa >= xe) return;
+    static_assert(FDW_PIPE_ROWS == 1, "one row per barrier");
+    __shared__ f4 linkF[NS][2][2][1][64];
+    __shared__ f4 linkR[NS][2][2][1][64];
+    __shared__ f4 fifo[kFusedFifoRows][64];
+    __shared__ f4 imf[16][64];
+    const int cs = zb * (64 - 2 * NS) - NS;
+    if (k8 < NS) marchn<H, NS, false, 0, PF, false, 3>(a, lane, k8, cs, xa, xe, linkF, fifo);
+    else marchn<H, NS, true, 2, PF, false, 4>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
+}
+
 hipError_t launch_stepn(const Step2Args& a, int h, int mode, hipStream_t s)
 {
     if (a.nper <= 0) return hipSuccess;
@@ -364,6 +406,7 @@ hipError_t launch_stepn(const Step2Args& a, int h, int mode, hipStream_t s)
     case FDW_MODE_MOD:   hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 3, FDW_PIPE_PF, true>), grid, block, 0, s, a); break;
     case FDW_MODE_PLAIN_ALL: hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, false, 0, FDW_PIPE_PF, false, 1>), grid, block, 0, s, a); break;
     case FDW_MODE_RECV:  hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 2, FDW_PIPE_PF, false, 2>), grid, block, 0, s, a); break;
+    case FDW_MODE_BACK4: hipLaunchKernelGGL((fdw_back4_kernel<4, kPipeSteps, FDW_PIPE_PF>), grid, dim3(128 * kPipeSteps), 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -7,7 +7,7 @@ import parallel_finite_difference_computation_amd as F
 n, nb = (int(sys.argv[1]) if len(sys.argv) > 1 else 8192), 64
 nt = 400
 ctx = F.FDWave(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 1e-3, compat=False)
-ctx.set_tuning(two_step=int(os.environ.get("TB_MODE", "0")))    # -1: one-step kernels only (fused backward iteration at any size)
+ctx.set_tuning(two_step=int(os.environ.get("TB_MODE", "0")), xchunk=int(os.environ.get("XCHUNK", "0")))    # -1: one-step kernels only (fused backward iteration at any size)
 rng = np.random.default_rng(0)
 v2 = np.full((n, n), 2500.0 ** 2, np.float32)
 s0 = (1e-3 * rng.standard_normal((n, n))).astype(np.float32); s1 = (1e-3 * rng.standard_normal((n, n))).astype(np.float32)

@@ -965,9 +965,10 @@ def test_fused_backward_iteration_equals_two_launches(order, monkeypatch):
 @pytest.mark.parametrize("case", [(150, 1300, 20, 24, 23, True, 10.0, 10.0), (260, 530, 24, 40, 18, False, 25.0, 8.0), (99, 83, 17, 13, 15, True, 10.0, 10.0),
                                   (333, 700, 40, 16, 14, True, 8.0, 12.5)], ids=lambda c: "x".join(map(str, c)))
 def test_backward_wave_pipeline_vs_oracle(case, monkeypatch):
-    """The backward loop four iterations at a time through the wave pipeline (pass 1: the source field, all four levels kept; pass 2: the
-    receiver field with per-level trace injection and the four imaging products added in iteration order through the LDS FIFO), forced on
-    small decks: image equal to the oracle's bit for bit for iteration counts that leave 0..3 iterations to the pair / single kernels,
+    """The backward loop four iterations at a time through the wave pipeline -- the fused eight-wave kernel (source-field and receiver-field
+    pipelines side by side, the levels in between handed over in LDS) and its two-pass form (pass 1: the source field, all four levels kept;
+    pass 2: the receiver field with per-level trace injection and the four imaging products added in iteration order through the LDS FIFO)
+    -- forced on small decks: image equal to the oracle's bit for bit for iteration counts that leave 0..3 iterations to the pair / single kernels,
     onto a non-zero start image, several chunk lengths; FDW_NO_BACK_PIPE=1 gives the same image."""
     nxe, nze, nxb, nzb, nt, compat, dx, dz = case
     d = make_deck(nxe, nze, nxb, nzb, nt, seed=77, compat=compat, dx=dx, dz=dz)
@@ -986,10 +987,19 @@ def test_backward_wave_pipeline_vs_oracle(case, monkeypatch):
     ctx.set_tuning(two_step=4)
     img, P, PP = ctx.shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs, imloc=im0, want_fields=True)
     assert_bit_equal(img, orc.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0), "shot image with both loops on the wave pipeline")
+    want = orc.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0)
+    monkeypatch.setenv("FDW_NO_BACK_FUSED", "1")      # the two-pass form of the pipeline (source-field pass keeping four levels, receiver pass)
+    two = mk(d)
+    monkeypatch.delenv("FDW_NO_BACK_FUSED")
+    for n in (nt, 7, 10):
+        for xchunk in (0, 13):
+            two.set_tuning(two_step=4, xchunk=xchunk)
+            assert_bit_equal(two.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n), orc.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0, nsteps=n),
+                             f"two-pass pipelined backward loop, {n} iterations, xchunk {xchunk}")
     monkeypatch.setenv("FDW_NO_BACK_PIPE", "1")
     off = mk(d)
     off.set_tuning(two_step=4)
-    assert_bit_equal(off.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0), orc.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0), "FDW_NO_BACK_PIPE=1")
+    assert_bit_equal(off.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0), want, "FDW_NO_BACK_PIPE=1")
 
 
 @pytest.mark.parametrize("spacing", [(25.0, 8.0), (8.0, 25.0)], ids=["marmousi-dx25-dz8", "dx8-dz25"])
