@@ -707,6 +707,13 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
     // measured: 16384^2 579 Gpt/s at 253 (560 at 173); 8192^2 566 at 173 (509 at 83, 553 at 253); 4096^2 452 at 83 (382 at 43, 388 at 173);
     // 1056x8192 371 at 43 (355 at 63, 340 at 33)
     int xchunk = c->xchunk2 > 0 ? c->xchunk2 : (strip_rows >= 1000000 ? 253 : (strip_rows >= 250000 ? 173 : (strip_rows >= 60000 ? 83 : 43)));
+    if (mode == FDW_MODE_BACK4 && c->xchunk2 <= 0) {
+        // the eight-wave kernel holds two workgroups per CU (512 at a time): longer chunks than the forward kernel's at the same grid size
+        // (scripts/probe_slabs_c.py, us per iteration by chunk length 43 / 83 / 123 / 173: 8192 rows 363 / 309 / 289 / 277; 4160 rows 192 / 172 / 157 / 162;
+        //  2176 rows 109 / 94 / 102 / 93; 1152 rows 61 / 64 / 69 / 80)
+        xchunk = strip_rows >= 250000 ? 173 : (strip_rows >= 120000 ? 123 : (strip_rows >= 60000 ? 83 : 43));
+        if (const char* e = getenv("FDW_BACK4_XCHUNK")) xchunk = atoi(e) > 0 ? atoi(e) : xchunk;      // experiments
+    }
     if (rr.xchunk > 0) xchunk = rr.xchunk;
     a.xchunk = xchunk;
     a.chunks_a = (rows_a + xchunk - 1) / xchunk;

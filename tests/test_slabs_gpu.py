@@ -28,8 +28,9 @@ def _single(d, srce, d_obs, im0):
 
 
 @pytest.mark.parametrize("world,ksteps,shape,compat,pipe", [(2, 4, (400, 500), True, False), (3, 3, (701, 523), True, False), (4, 0, (640, 300), False, False),
-                                                            (3, 8, (900, 2100), False, True), (2, 4, (333, 2500), True, True)],
-                         ids=["2ranks-k4", "3ranks-k3-ragged", "4ranks-auto", "3ranks-pipeline-k8", "2ranks-pipeline-k4-ragged"])
+                                                            (3, 8, (900, 2100), False, True), (2, 4, (333, 2500), True, True),
+                                                            (8, 4, (1024, 300), False, False), (8, 4, (1100, 2300), True, True)],
+                         ids=["2ranks-k4", "3ranks-k3-ragged", "4ranks-auto", "3ranks-pipeline-k8", "2ranks-pipeline-k4-ragged", "8ranks-k4", "8ranks-pipeline-k4-ragged"])
 def test_c_slab_driver_ranks_as_threads_on_one_gpu(world, ksteps, shape, compat, pipe, monkeypatch):
     """fdw_slabs_shot (forward loop, snapshots, backward loop with imaging, every halo exchange enqueued by the C library) on `world`
     ranks = host threads sharing this GPU: the image, P and PP gathered from the ranks' owned rows equal fdw_shot's on the whole grid bit
