@@ -179,8 +179,9 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         const int r = rk + m;
         constexpr int SLOT = U % ROWS;                          // which of the ROWS rows between two barriers
         const int par = (m / ROWS) & 1;                          // link buffers alternate per barrier interval
-        const bool act = !(FDW_PIPE_OPT & 1) || ((m >= m_lo) && (m < m_hi));
-        const bool fill = !(FDW_PIPE_OPT & 1) || ((m >= m_lo - 2 * H) && (m < m_hi));     // collecting the rows that enter the window
+        constexpr bool SKIP = (FDW_PIPE_OPT & 1) && (!DD || (FDW_PIPE_OPT & 16));   // (the modelling dialect measured 5 % slower with it: its scalar Laplacian leaves no slack)
+        const bool act = !SKIP || ((m >= m_lo) && (m < m_hi));
+        const bool fill = !SKIP || ((m >= m_lo - 2 * H) && (m < m_hi));                   // collecting the rows that enter the window
         // ---- what the previous wave handed over during march step m-1: the row entering this wave's window ----
         if (fill) {
 #if !(FDW_ABL_BITS & 128)
