@@ -105,3 +105,55 @@ def test_local_communicator_selftest_and_errors():
         F.run_ranks(lambda r: F.Slabs(8, 60, 64, 8, 8, 4, 0.75, 10.0, 10.0, 0.001, comm=comms[r], ksteps=8), 3)
     for c in comms:
         c.close()
+
+
+def test_random_slab_decompositions_property(monkeypatch):
+    """Property test over the C slab driver: randomly drawn grids (ragged extents, truncated or full launch grids, dx != dz), world sizes,
+    steps per exchange (given or chosen by the library), with and without the pipeline kernels inside the slabs -- the image, P and PP
+    gathered from the ranks (host threads on this GPU) equal fdw_shot on the whole grid bit for bit."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+
+    @st.composite
+    def cases(draw):
+        world = draw(st.integers(2, 5))
+        pipe = draw(st.booleans())
+        k = draw(st.sampled_from([4, 8] if pipe else [0, 1, 2, 3, 5, 8]))
+        nb = draw(st.sampled_from([16, 24, 40]))
+        min_rows = world * (2 * 4 * max(k, 4) + 16)
+        nxe = draw(st.integers(max(min_rows, 2 * nb + 40), max(min_rows, 2 * nb + 40) + 300))
+        nze = draw(st.integers(2 * nb + 30, 900))
+        return dict(world=world, pipe=pipe, k=k, nb=nb, nxe=nxe, nze=nze, compat=draw(st.booleans()),
+                    spacing=draw(st.sampled_from([(10.0, 10.0), (25.0, 8.0)])), nt=draw(st.integers(3, 26)), seed=draw(st.integers(0, 10**6)))
+
+    seen = []
+
+    @settings(max_examples=int(__import__("os").environ.get("FDW_PROPERTY_EXAMPLES", "40")), deadline=None, suppress_health_check=list(HealthCheck),
+              derandomize="FDW_PROPERTY_RANDOM" not in __import__("os").environ, database=None)
+    @given(cases())
+    def check(c):
+        seen.append((c["world"], c["pipe"]))
+        d, srce, d_obs, im0 = _case(c["nxe"], c["nze"], c["nb"], c["nt"], c["compat"], seed=c["seed"], dx=c["spacing"][0], dz=c["spacing"][1])
+        want, P, PP = _single(d, srce, d_obs, im0)
+        monkeypatch.setenv("FDW_SLAB_PIPE", "1" if c["pipe"] else "0")
+        comms = F.Comm.local(c["world"])
+
+        def rank(r):
+            s = F.Slabs(d["order"], c["nxe"], c["nze"], d["nxb"], d["nzb"], c["nt"], d["fac"], d["dx"], d["dz"], d["dt"], comm=comms[r], compat=c["compat"], ksteps=c["k"])
+            out = s.shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs, imloc=im0, want_fields=True)
+            geo = (s.own0, s.own1, s.owned_interior_rows())
+            s.close()
+            return out, geo
+
+        res = F.run_ranks(rank, c["world"])
+        img, gP, gPP = np.array(im0), np.zeros_like(P), np.zeros_like(PP)
+        for (im, p, pp), (o0, o1, (a, b)) in res:
+            img[a:b] = im[a:b]
+            gP[o0:o1], gPP[o0:o1] = p[o0:o1], pp[o0:o1]
+        for cm in comms:
+            cm.close()
+        assert_bit_equal(gPP, PP, f"PP {c}")
+        assert_bit_equal(gP, P, f"P {c}")
+        assert_bit_equal(img, want, f"image {c}")
+
+    check()
+    assert {p for _, p in seen} == {True, False} and len({w for w, _ in seen}) >= 3
