@@ -27,7 +27,8 @@ namespace fdw {
 #define FDW_PIPE_PF 2      // rows of global look-ahead of wave 0
 #endif
 #ifndef FDW_PIPE_OPT
-#define FDW_PIPE_OPT 1     // 1: waves skip the march steps outside their useful window; 4: the frame masks only in workgroups that touch the frame
+#define FDW_PIPE_OPT 33    // 1: waves skip the march steps outside their useful window; 4: the frame masks only in workgroups that touch the frame;
+                           // 32: workgroups away from the frame, the damped strip and the sources run the lean body (pipe_lean)
 #endif                     //    (measured slower: 581 vs 590 Gpoints/s at 8192^2)
 #ifndef FDW_PIPE_ROWS
 #define FDW_PIPE_ROWS 1    // march steps between two workgroup barriers of the pipeline kernel (1 or 2)
@@ -48,10 +49,13 @@ __device__ __forceinline__ int pipe_fifo_slot(int m)
 // wave 0 fills the shared v2 FIFO, every wave's new row also serves the receiver wave of its level), 4 = receiver field (one march step
 // behind: its rows, windows and FIFO slots are those of role 3 shifted by D = 1, so that the source-field row it images against was
 // written to the link buffers during the step before; v2 for all four waves from the FIFO; image as in BK 2)
-template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0, int ROWS = FDW_PIPE_ROWS>
+// LEAN: the body for workgroups that touch neither the frame of the grid (no Laplacian / update masks, no row clamps), nor the damped strip,
+// nor the source (instantiate with TAPER = false, INJ = 0): the kernel picks it per workgroup (pipe_lean)
+template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0, int ROWS = FDW_PIPE_ROWS, bool LEAN = false>
 __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const int k, const int cs, const int xa, const int xe,
                                        f4 (*link)[2][2][ROWS][64], f4 (*fifo)[64], f4 (*imf)[64] = nullptr, f4 (*linkx)[2][2][ROWS][64] = nullptr)
 {
+    static_assert(!LEAN || (!TAPER && INJ == 0 && !DD), "the lean body has no damping, no injection and the RTM arithmetic");
     constexpr bool IMG = (BK == 2 || BK == 4);
     constexpr int D = (BK == 4) ? 1 : 0;                      // this role runs D march steps behind
     constexpr int DL = (BK >= 3) ? 1 : 0;                     // ... so both roles of the fused kernel loop one step longer
@@ -119,7 +123,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             for (int e = 0; e < 4; ++e) v.v[e] = taper1(v.v[e], tzc[e], znc[e], rowtz, txr);
         }
     };
-    auto rowoff = [&](int row) -> unsigned { return (unsigned)min(max(row, 0), rowmax) * row_bytes; };
+    auto rowoff = [&](int row) -> unsigned { return LEAN ? (unsigned)row * row_bytes : (unsigned)min(max(row, 0), rowmax) * row_bytes; };
     auto load_p = [&](int row) -> f4 { return f4_load_arr(rs_p, loff, rowoff(row), (FDW_NT & 4) != 0); };
     auto load_pw = [&](__amdgpu_buffer_rsrc_t rs, int row) -> f4 { return f4_load_arr(rs, loff, rowoff(row), (FDW_NT & 1) != 0); };
 
@@ -168,8 +172,8 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
     const int m_lo = k * (2 * H + ROWS) + D, m_hi = (xe - xa) + 2 * (NS - 1) * H + k * ROWS + D;
     // The frame of the grid (rows / columns where the Laplacian or the update is masked) only concerns the workgroups that touch it;
     // all others take the wave-uniform branch around the mask selects.
-    const bool edge = !(FDW_PIPE_OPT & 4) || (cs * 4 < a.lap_z0) || (cs * 4 + 256 > min(a.lap_z1, a.upd_z1)) || (xa - (NS - 1) * H - NS * SK < max(a.lap_x0, 0)) ||
-                      (xe + (NS - 1) * H + NS * SK > min(a.lap_x1, a.upd_x1));
+    const bool edge = !LEAN && (!(FDW_PIPE_OPT & 4) || (cs * 4 < a.lap_z0) || (cs * 4 + 256 > min(a.lap_z1, a.upd_z1)) || (xa - (NS - 1) * H - NS * SK < max(a.lap_x0, 0)) ||
+                      (xe + (NS - 1) * H + NS * SK > min(a.lap_x1, a.upd_x1)));
 
     auto row_step = [&](const int mb, auto UU) {
         constexpr int U = decltype(UU)::value;
@@ -227,8 +231,8 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             rgt.v[e] = __shfl_down(c1.v[e], 1, 64);
 #endif
         }
-        const bool rowok = (r >= a.lap_x0) && (r < a.lap_x1);
-        const bool rowupd = (r >= 0) && (r < a.upd_x1);
+        const bool rowok = LEAN || ((r >= a.lap_x0) && (r < a.lap_x1));
+        const bool rowupd = LEAN || ((r >= 0) && (r < a.upd_x1));
         if constexpr (DD) {
             // this wave's p field is P of iteration it0 + k: its trace sample (mod_main.cpp:155-157); owned lanes and rows only
             if (rec_here && own && r >= xa && r < xe && r >= a.rec_x0 && r < a.rec_x0 + a.rec_n) {
@@ -256,13 +260,14 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             static_for<2>([&](auto PP) {
                 constexpr int P = decltype(PP)::value;
                 v2f lap2 = lapq[P];
-                if (edge) lap2 = v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
+                if constexpr (!LEAN)
+                    if (edge) lap2 = v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
                 const v2f prod2 = (f4_pair(v2t, P) * a.dt2) * lap2;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int e = 2 * P + q;
                     const float upd = leapfrog_prod(c1.v[e], ppt.v[e], q ? prod2.y : prod2.x);
-                    u.v[e] = (!edge || (rowupd && mupd[e])) ? upd : ppt.v[e];
+                    u.v[e] = (LEAN || !edge || (rowupd && mupd[e])) ? upd : ppt.v[e];
                 }
             });
         }
@@ -343,6 +348,21 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         static_for<R>([&](auto UU) { row_step(mb, UU); });
 }
 
+// Workgroup-uniform: may this tile run the lean body?  Every row it touches -- stencil taps, look-ahead loads (PF + ring rows beyond the
+// chunk) -- lies inside the rows where the Laplacian and the update are unmasked, its columns likewise, it is outside the damped strip, and
+// the source (INJ 1) is not in it.
+template <int H, int NS, bool TAPER, int INJ>
+__device__ __forceinline__ bool pipe_lean(const Step2Args& a, int cs, int xa, int xe)
+{
+    const int lo = xa - (NS - 1) * H - H - NS * (H + FDW_PIPE_ROWS), hi = xe + (NS - 1) * (2 * H + FDW_PIPE_ROWS) + 2 * H + 16;
+    bool ok = (cs * 4 >= a.lap_z0) && (cs * 4 + 256 <= min(a.lap_z1, a.upd_z1)) && (lo >= max(a.lap_x0, 0)) && (hi <= min(min(a.lap_x1, a.upd_x1), a.nxl));
+    if (TAPER) ok = ok && (cs * 4 >= a.ztap);
+    if (INJ > 2) return false;
+    if (INJ == 2) ok = ok && !((a.inj_z >= cs * 4) && (a.inj_z < cs * 4 + 256) && (a.inj_x < xe + NS * H) && (a.inj_x + a.inj_n > xa - NS * H));
+    if (INJ == 1) ok = ok && !((a.inj_z >= cs * 4) && (a.inj_z < cs * 4 + 256) && (a.inj_x >= xa - NS * H) && (a.inj_x < xe + NS * H));
+    return ok;
+}
+
 template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0>
 __global__ __launch_bounds__(64 * NS, (FDW_PIPE_ROWS != 1 || BK == 2) ? 3 : (DD ? 4 : 5)) void fdw_stepn_kernel(const Step2Args a)
 {
@@ -363,6 +383,11 @@ __global__ __launch_bounds__(64 * NS, (FDW_PIPE_ROWS != 1 || BK == 2) ? 3 : (DD 
         static_assert(FDW_PIPE_ROWS == 1, "the image FIFO assumes one row per barrier");
         __shared__ f4 imf[16][64];                         // image rows on their way from wave to wave (a row is 3 (H + 1) = 15 steps under way)
         marchn<H, NS, TAPER, INJ, PF, DD, BK>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo, imf);
+    } else if constexpr (BK == 0 && !DD && (FDW_PIPE_OPT & 32)) {
+        // nine workgroups in ten of a large grid touch neither the frame, nor the damped strip, nor the source: they take the lean body
+        const int cs = zb * (64 - 2 * NS) - NS;
+        if (pipe_lean<H, NS, TAPER, INJ>(a, cs, xa, xe)) marchn<H, NS, false, 0, PF, false, 0, FDW_PIPE_ROWS, true>(a, lane, k, cs, xa, xe, link, fifo);
+        else marchn<H, NS, TAPER, INJ, PF, DD, BK>(a, lane, k, cs, xa, xe, link, fifo);
     } else {
         marchn<H, NS, TAPER, INJ, PF, DD, BK>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo);
     }
@@ -392,8 +417,15 @@ __global__ __launch_bounds__(128 * NS, 2) void fdw_back4_kernel(const Step2Args 
     __shared__ f4 fifo[kFusedFifoRows][64];
     __shared__ f4 imf[16][64];
     const int cs = zb * (64 - 2 * NS) - NS;
-    if (k8 < NS) marchn<H, NS, false, 0, PF, false, 3>(a, lane, k8, cs, xa, xe, linkF, fifo);
-    else marchn<H, NS, true, 2, PF, false, 4>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
+    constexpr bool kLean = (FDW_PIPE_OPT & 32) != 0;
+    if (k8 < NS) {
+        if (kLean && pipe_lean<H, NS, false, 0>(a, cs, xa, xe)) marchn<H, NS, false, 0, PF, false, 3, 1, true>(a, lane, k8, cs, xa, xe, linkF, fifo);
+        else marchn<H, NS, false, 0, PF, false, 3>(a, lane, k8, cs, xa, xe, linkF, fifo);
+    } else {
+        // receiver role: lean where the tile holds neither the damped strip nor the receiver line
+        if (kLean && pipe_lean<H, NS, true, 2>(a, cs, xa, xe)) marchn<H, NS, false, 0, PF, false, 4, 1, true>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
+        else marchn<H, NS, true, 2, PF, false, 4>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
+    }
 }
 
 hipError_t launch_stepn(const Step2Args& a, int h, int mode, hipStream_t s)
