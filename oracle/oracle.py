@@ -221,6 +221,41 @@ def mod_shot(order, nx, nz, nxb, nzb, dx, dz, dt, fac, vel2, sx, sz, gz, srce):
     return data
 
 
+def mod_steps(order, nx, nz, nxb, nzb, dx, dz, dt, fac, vel2, sx, sz, gz, srce, P, PP):
+    """nsteps = len(srce) iterations of mod_main's loop (mod_main.cpp:147-164) from the given P / PP (as the loop holds them on entry):
+    returns (P, PP, data[nx][nsteps]) as the loop holds them after the last swap."""
+    L = lib()
+    nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+    P, PP = np.array(P, np.float32, order="C"), np.array(PP, np.float32, order="C")
+    vel2 = np.ascontiguousarray(vel2, np.float32)
+    srce = np.ascontiguousarray(srce, np.float32)
+    tx, tz = np.ones(max(nxb, 1), np.float32), np.ones(max(nzb, 1), np.float32)
+    L.orc_mod_taper_tables(nxb, nzb, fac, tx, tz)
+    coefs = calc_coefs(order, cxx=True)
+    f = np.float32
+    dx2inv, dz2inv, dt2 = f((1. / dx) * (1. / dx)), f((1. / dz) * (1. / dz)), f(f(dt) * f(dt))      # fd.c:13-15
+    lap = np.zeros((nxe, nze), np.float32)
+    data = np.zeros((nx, srce.size), np.float32)
+    for it in range(srce.size):
+        L.orc_mod_fd_step(order, coefs, dx2inv, dz2inv, dt2, P, PP, vel2, lap, nze, nxe)
+        L.orc_mod_ptsrc(sx, sz, nxe, nze, srce[it], PP)
+        L.orc_mod_taper_apply(PP, nx, nz, nxb, nzb, tx, tz)
+        L.orc_mod_taper_apply(P, nx, nz, nxb, nzb, tx, tz)
+        data[:, it] = P[nxb:nxb + nx, gz]
+        P, PP = PP, P
+    return P, PP, data
+
+
+def mod_taper_apply(field, nx, nz, nxb, nzb, fac, times=1):
+    """taper_apply (taper.c:46-66) `times` times, on a copy."""
+    tx, tz = np.ones(max(nxb, 1), np.float32), np.ones(max(nzb, 1), np.float32)
+    lib().orc_mod_taper_tables(nxb, nzb, fac, tx, tz)
+    out = np.array(field, np.float32, order="C")
+    for _ in range(times):
+        lib().orc_mod_taper_apply(out, nx, nz, nxb, nzb, tx, tz)
+    return out
+
+
 def rtm_stored_shot(order, nx, nz, nxb, nzb, dx, dz, dt, fac, vel2, sx, sz, gz, srce, dobs, shot=0):
     """rtm_main's loop for one shot (rtm_main.cpp:158-240): imloc[nx][nz]; dobs is the whole gather [ns][nx][nt]."""
     srce = np.ascontiguousarray(srce, np.float32)

@@ -656,6 +656,11 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
     a.lap_x0 = c->lap_x0; a.lap_x1 = c->lap_x1; a.lap_z0 = c->lap_z0; a.lap_z1 = c->lap_z1;
     a.upd_x1 = c->upd_x1; a.upd_z1 = c->upd_z1;
     a.ztap = c->ztap; a.tz_x1 = c->tz_x1; a.xt_lo = c->xt_lo; a.xt_hi = c->xt_hi;
+    {   // columns without a damping factor (taper_apply's table is 1.0f between the two strips; the RTM dialects damp the top strip only)
+        const bool four_sided = c->prm.dialect == FDW_DIALECT_MOD;
+        a.zt_lo = four_sided ? c->prm.nzb : c->ztap;
+        a.zt_hi = four_sided ? c->prm.nze - c->prm.nzb : -1;
+    }
     a.pp_twice = pp_twice ? 1 : 0;
     a.inj_x = -1000000; a.inj_z = inj_z; a.inj_n = 0;
     if (mode == FDW_MODE_FWD && d_inj && inj_x_global >= 0) {

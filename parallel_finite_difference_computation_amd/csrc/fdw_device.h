@@ -265,6 +265,27 @@ __device__ __forceinline__ void laplacian_quad(const ZPairs& z, Row&& row, const
     lap23 = az1 + ax1;
 }
 
+// The CPU-serial sibling's Laplacian (laplacian_dd_pt above; fd.c:28-36) for the lane's two pairs: one accumulator chain per pair, per
+// tap the z term then the x term, each (value * weight) * inverse spacing squared -- the same individually rounded operations in the
+// same order, two cells per instruction.  c.z = the unscaled weights; inv = (dz2inv, dx2inv) in an SGPR pair.
+template <int H, class Row>
+__device__ __forceinline__ void laplacian_dd_quad(const ZPairs& z, Row&& row, const CoefPairs<H>& c, v2f inv, v2f& lap01, v2f& lap23)
+{
+    v2f a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
+    static_for<2 * H + 1>([&](auto IO) {
+        constexpr int io = decltype(IO)::value;
+        constexpr int k0 = 4 - H + io, k1 = 6 - H + io;
+        constexpr int ic = io <= H ? io : 2 * H - io;
+        const f4 r = row(IO);
+        a0 = a0 + pk_mul_sel<0>(pk_mul_sel<ic & 1>((k0 & 1) ? z.O[k0 >> 1] : z.E[k0 >> 1], c.z[ic >> 1]), inv);
+        a1 = a1 + pk_mul_sel<0>(pk_mul_sel<ic & 1>((k1 & 1) ? z.O[k1 >> 1] : z.E[k1 >> 1], c.z[ic >> 1]), inv);
+        a0 = a0 + pk_mul_sel<1>(pk_mul_sel<ic & 1>(v2f{r.v[0], r.v[1]}, c.z[ic >> 1]), inv);
+        a1 = a1 + pk_mul_sel<1>(pk_mul_sel<ic & 1>(v2f{r.v[2], r.v[3]}, c.z[ic >> 1]), inv);
+    });
+    lap01 = a0;
+    lap23 = a1;
+}
+
 // ring geometry: PF rows of pointwise look-ahead (pp, v2, halo, ...); the p ring holds R rows,
 // R a multiple of PF (so queue slots are compile-time constants) and >= 2H+PF.
 template <int H, int PF>

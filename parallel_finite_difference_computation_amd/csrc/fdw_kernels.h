@@ -80,6 +80,7 @@ struct Step2Args {
     int lap_x0, lap_x1, lap_z0, lap_z1;
     int upd_x1, upd_z1;
     int ztap, tz_x1, xt_lo, xt_hi;
+    int zt_lo, zt_hi;      // pipeline kernel: columns [zt_lo, zt_hi) carry no damping factor (zt_hi < 0: no x factor outside the damped strip either)
     int pp_twice;
     int inj_x, inj_z, inj_n;
     int xchunk, nstrip, nzblk, nblk, nper;

@@ -26,9 +26,14 @@ namespace fdw {
 #ifndef FDW_PIPE_PF
 #define FDW_PIPE_PF 2      // rows of global look-ahead of wave 0
 #endif
+#ifndef FDW_DD_WG
+#define FDW_DD_WG 4
+#endif
 #ifndef FDW_PIPE_OPT
-#define FDW_PIPE_OPT 33    // 1: waves skip the march steps outside their useful window; 4: the frame masks only in workgroups that touch the frame;
-                           // 32: workgroups away from the frame, the damped strip and the sources run the lean body (pipe_lean)
+#define FDW_PIPE_OPT 481   // 1: waves skip the march steps outside their useful window; 4: the frame masks only in workgroups that touch the frame;
+                           // 32: workgroups away from the frame, the damped strip and the sources run the lean body (pipe_lean);
+                           // 64: neighbouring lanes' values through DPP (v_mov_b32_dpp wave_shr / wave_shl) instead of ds_bpermute_b32;
+                           // 128 / 256: the lean body compiled once for wave 0 and once for the other waves (forward / fused backward kernel)
 #endif                     //    (measured slower: 581 vs 590 Gpoints/s at 8192^2)
 #ifndef FDW_PIPE_ROWS
 #define FDW_PIPE_ROWS 1    // march steps between two workgroup barriers of the pipeline kernel (1 or 2)
@@ -49,13 +54,22 @@ __device__ __forceinline__ int pipe_fifo_slot(int m)
 // wave 0 fills the shared v2 FIFO, every wave's new row also serves the receiver wave of its level), 4 = receiver field (one march step
 // behind: its rows, windows and FIFO slots are those of role 3 shifted by D = 1, so that the source-field row it images against was
 // written to the link buffers during the step before; v2 for all four waves from the FIFO; image as in BK 2)
+// The neighbouring lane's value through the VALU's DPP path (v_mov_b32_dpp wave_shr:1 / wave_shl:1) instead of the LDS crossbar
+// (ds_bpermute_b32, what __shfl_up / __shfl_down compile to).  Lane 0 (63) has no source and reads 0: both are halo lanes.
+template <int CTRL>
+__device__ __forceinline__ float lane_shift(float x)
+{
+    // bound_ctrl: the lane without a source reads 0, so the builtin's "old" operand is dead and costs no initialising v_mov
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+
 // LEAN: the body for workgroups that touch neither the frame of the grid (no Laplacian / update masks, no row clamps), nor the damped strip,
 // nor the source (instantiate with TAPER = false, INJ = 0): the kernel picks it per workgroup (pipe_lean)
-template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0, int ROWS = FDW_PIPE_ROWS, bool LEAN = false>
+template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0, int ROWS = FDW_PIPE_ROWS, bool LEAN = false, int WK = 0>
 __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const int k, const int cs, const int xa, const int xe,
                                        f4 (*link)[2][2][ROWS][64], f4 (*fifo)[64], f4 (*imf)[64] = nullptr, f4 (*linkx)[2][2][ROWS][64] = nullptr)
 {
-    static_assert(!LEAN || (!TAPER && INJ == 0 && !DD), "the lean body has no damping, no injection and the RTM arithmetic");
+    static_assert(!LEAN || (!TAPER && INJ == 0), "the lean body has no damping, no injection (and records no trace)");
     constexpr bool IMG = (BK == 2 || BK == 4);
     constexpr int D = (BK == 4) ? 1 : 0;                      // this role runs D march steps behind
     constexpr int DL = (BK >= 3) ? 1 : 0;                     // ... so both roles of the fused kernel loop one step longer
@@ -67,7 +81,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
     constexpr int FD = BK >= 3 ? kFusedFifoRows : pipe_fifo_rows(NS, H, ROWS);
     static_assert(ROWS == 1 || (ROWS == 2 && R % 2 == 0), "one or two rows per barrier");
     static_assert(BK < 3 || ROWS == 1, "the fused backward kernel assumes one row per barrier");
-    const bool first = (k == 0);
+    const bool first = WK == 1 ? true : (WK == 2 ? false : (k == 0));      // WK 1 / 2: the body compiled for wave 0 / for the other waves
     const int cell = cs + lane;
     const int z0 = cell * 4;
     const unsigned voff = (unsigned)min(max(z0, 0), a.pitch - 4) * 4u;
@@ -87,13 +101,14 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
 
     const bool wave_tap = TAPER && (cs * 4 < a.ztap);
     const bool xtap = wave_tap && ((xa - NS * H < a.xt_lo) || (xe + NS * H > a.xt_hi));
-    const CoefPairs<H> cpk = coef_pairs<H>(a.cx, a.cz);
+    const CoefPairs<H> cpk = DD ? coef_pairs<H>(a.cz, a.cz) : coef_pairs<H>(a.cx, a.cz);      // DD: the unscaled weights (the spacings enter per term)
+    const v2f ddinv = v2f{a.dz2inv, a.dx2inv};
     const int blob = (INJ == 3) ? 3 : 0;                                  // INJ 3: 7x7 Gaussian source of the CPU-serial sibling (ptsrc.c:49-55)
     const bool inj_here = (INJ == 2) ? ((a.inj_z >= cs * 4) && (a.inj_z < cs * 4 + 256) && (a.inj_x < xe + NS * H) && (a.inj_x + a.inj_n > xa - NS * H))
                                      : ((INJ != 0) && (a.inj_z + blob >= cs * 4) && (a.inj_z - blob < cs * 4 + 256) && (a.inj_x + blob >= xa - NS * H) && (a.inj_x - blob < xe + NS * H));
     const float injv = (INJ != 2 && inj_here) ? sload(a.inj, k) : 0.0f;    // source sample of this wave's time step (R:119-122)
     const float* injk = a.inj + (INJ == 2 ? k * a.inj_stride : 0);        // INJ 2: the trace samples of iteration it + k (R:124-131)
-    const bool rec_here = DD && (a.rec != nullptr) && (a.rec_z >= cs * 4) && (a.rec_z < cs * 4 + 256);
+    const bool rec_here = DD && !LEAN && (a.rec != nullptr) && (a.rec_z >= cs * 4) && (a.rec_z < cs * 4 + 256);
 
     bool mlap[4], mupd[4], znc[4], ihit[4];
     float tzc[4];
@@ -197,13 +212,13 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         float im0, im1, im2, im3;                               // the image row (BK 2, 4), as scalars: defined on every path without an instruction
         if constexpr (IMG) asm volatile("" : "=v"(im0), "=v"(im1), "=v"(im2), "=v"(im3));
         if (act) {
-        f4 ppt, v2t;
-        if (first) {                                            // wave 0: its rows come from global memory (loaded PF steps ago)
-            ppt = qpp[Q];
+        // pp and v2 of this row live in the look-ahead queue's registers: wave 0 finds them there (loaded PF steps ago), the other waves
+        // read theirs from LDS into the same registers (their own look-ahead loads are switched off and return nothing they need)
+        f4 &ppt = qpp[Q], &v2t = qv2[Q];
+        if (first) {
             if constexpr (BK == 4) {
                 v2t = fifo[pipe_fifo_slot<FD>(m - D)][lane];     // the source-field role's wave 0 parked it one step ago
             } else {
-                v2t = qv2[Q];
 #if !(FDW_ABL_BITS & 128)
                 fifo[pipe_fifo_slot<FD>(m)][lane] = qv2[Q];
 #endif
@@ -226,6 +241,9 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         for (int e = 0; e < 4; ++e) {
 #if FDW_ABL_BITS & 2048
             lft.v[e] = c1.v[(e + 1) & 3]; rgt.v[e] = c1.v[(e + 2) & 3];
+#elif FDW_PIPE_OPT & 64
+            lft.v[e] = lane_shift<0x138>(c1.v[e]);              // wave_shr:1 -- lane i takes lane i-1's
+            rgt.v[e] = lane_shift<0x130>(c1.v[e]);              // wave_shl:1
 #else
             lft.v[e] = __shfl_up(c1.v[e], 1, 64);
             rgt.v[e] = __shfl_down(c1.v[e], 1, 64);
@@ -240,19 +258,22 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
                 for (int e = 0; e < 4; ++e)
                     if (z0 + e == a.rec_z) a.rec[k * a.rec_n + (r - a.rec_x0)] = c1.v[e];
             }
-            float W[12];
+            // the sibling's single-accumulator Laplacian, two cells per instruction (laplacian_dd_quad)
+            const ZPairs zp = zpairs(lft, c1, rgt);
+            v2f lapq[2];
+            laplacian_dd_quad<H>(zp, [&](auto IO) -> const f4& { return ring[(U + decltype(IO)::value) % R]; }, cpk, ddinv, lapq[0], lapq[1]);
+            static_for<2>([&](auto PP) {
+                constexpr int P = decltype(PP)::value;
+                v2f lap2 = lapq[P];
+                if constexpr (!LEAN) lap2 = v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
+                const v2f prod2 = (f4_pair(v2t, P) * a.dt2) * lap2;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { W[e] = lft.v[e]; W[4 + e] = c1.v[e]; W[8 + e] = rgt.v[e]; }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float col[2 * H + 1];
-#pragma unroll
-                for (int io = 0; io <= 2 * H; ++io) col[io] = ring[(U + io) % R].v[e];
-                float lap = laplacian_dd_pt<H>(W, e, col, a.cz, a.dx2inv, a.dz2inv);
-                lap = (rowok && mlap[e]) ? lap : 0.0f;
-                const float upd = leapfrog_prod(c1.v[e], ppt.v[e], (v2t.v[e] * a.dt2) * lap);
-                u.v[e] = (rowupd && mupd[e]) ? upd : ppt.v[e];
-            }
+                for (int q = 0; q < 2; ++q) {
+                    const int e = 2 * P + q;
+                    const float upd = leapfrog_prod(c1.v[e], ppt.v[e], q ? prod2.y : prod2.x);
+                    u.v[e] = (LEAN || (rowupd && mupd[e])) ? upd : ppt.v[e];
+                }
+            });
         } else {
             const ZPairs zp = zpairs(lft, c1, rgt);
             v2f lapq[2];
@@ -333,7 +354,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             f4_store_arr(rs_img, sim, rowoff(r), im);
         }
         // ---- look-ahead loads of wave 0 into the slots this step freed ----
-        ring[U] = load_p(b0 + m + R);
+        if constexpr (WK != 2) ring[U] = load_p(b0 + m + R);
         qpp[Q] = load_pw(rs_pp, s0 + m + PF);
         if constexpr (BK != 4) qv2[Q] = load_pw(rs_v2, s0 + m + PF);
         if constexpr (BK == 2) qlv[Q] = f4_load_arr(rs_lev, ioff, rowoff(r + PF), (FDW_NT & 1) != 0);
@@ -350,21 +371,26 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
 
 // Workgroup-uniform: may this tile run the lean body?  Every row it touches -- stencil taps, look-ahead loads (PF + ring rows beyond the
 // chunk) -- lies inside the rows where the Laplacian and the update are unmasked, its columns likewise, it is outside the damped strip, and
-// the source (INJ 1) is not in it.
-template <int H, int NS, bool TAPER, int INJ>
+// neither a source nor (modelling) the receiver line is in it.
+template <int H, int NS, bool TAPER, int INJ, bool DD = false>
 __device__ __forceinline__ bool pipe_lean(const Step2Args& a, int cs, int xa, int xe)
 {
     const int lo = xa - (NS - 1) * H - H - NS * (H + FDW_PIPE_ROWS), hi = xe + (NS - 1) * (2 * H + FDW_PIPE_ROWS) + 2 * H + 16;
-    bool ok = (cs * 4 >= a.lap_z0) && (cs * 4 + 256 <= min(a.lap_z1, a.upd_z1)) && (lo >= max(a.lap_x0, 0)) && (hi <= min(min(a.lap_x1, a.upd_x1), a.nxl));
-    if (TAPER) ok = ok && (cs * 4 >= a.ztap);
-    if (INJ > 2) return false;
-    if (INJ == 2) ok = ok && !((a.inj_z >= cs * 4) && (a.inj_z < cs * 4 + 256) && (a.inj_x < xe + NS * H) && (a.inj_x + a.inj_n > xa - NS * H));
-    if (INJ == 1) ok = ok && !((a.inj_z >= cs * 4) && (a.inj_z < cs * 4 + 256) && (a.inj_x >= xa - NS * H) && (a.inj_x < xe + NS * H));
+    const int c0 = cs * 4, c1 = cs * 4 + 256;
+    bool ok = (c0 >= a.lap_z0) && (c1 <= min(a.lap_z1, a.upd_z1)) && (lo >= max(a.lap_x0, 0)) && (hi <= min(min(a.lap_x1, a.upd_x1), a.nxl));
+    if (TAPER) {
+        ok = ok && (c0 >= a.zt_lo);
+        if (a.zt_hi >= 0) ok = ok && (c1 <= a.zt_hi) && (lo >= a.xt_lo) && (hi <= a.xt_hi);      // four-sided damping (taper_apply)
+    }
+    if (INJ == 3) ok = ok && !((a.inj_z + 3 >= c0) && (a.inj_z - 3 < c1) && (a.inj_x + 3 >= xa - NS * H) && (a.inj_x - 3 < xe + NS * H));
+    if (INJ == 2) ok = ok && !((a.inj_z >= c0) && (a.inj_z < c1) && (a.inj_x < xe + NS * H) && (a.inj_x + a.inj_n > xa - NS * H));
+    if (INJ == 1) ok = ok && !((a.inj_z >= c0) && (a.inj_z < c1) && (a.inj_x >= xa - NS * H) && (a.inj_x < xe + NS * H));
+    if (DD) ok = ok && !((a.rec != nullptr) && (a.rec_z >= c0) && (a.rec_z < c1));                  // trace recording
     return ok;
 }
 
 template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0>
-__global__ __launch_bounds__(64 * NS, (FDW_PIPE_ROWS != 1 || BK == 2) ? 3 : (DD ? 4 : 5)) void fdw_stepn_kernel(const Step2Args a)
+__global__ __launch_bounds__(64 * NS, (FDW_PIPE_ROWS != 1 || BK == 2) ? 3 : (DD ? FDW_DD_WG : 5)) void fdw_stepn_kernel(const Step2Args a)
 {
     const int lane = threadIdx.x & 63;
     const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -383,10 +409,17 @@ __global__ __launch_bounds__(64 * NS, (FDW_PIPE_ROWS != 1 || BK == 2) ? 3 : (DD 
         static_assert(FDW_PIPE_ROWS == 1, "the image FIFO assumes one row per barrier");
         __shared__ f4 imf[16][64];                         // image rows on their way from wave to wave (a row is 3 (H + 1) = 15 steps under way)
         marchn<H, NS, TAPER, INJ, PF, DD, BK>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo, imf);
-    } else if constexpr (BK == 0 && !DD && (FDW_PIPE_OPT & 32)) {
+    } else if constexpr (BK == 0 && (FDW_PIPE_OPT & 32)) {
         // nine workgroups in ten of a large grid touch neither the frame, nor the damped strip, nor the source: they take the lean body
         const int cs = zb * (64 - 2 * NS) - NS;
-        if (pipe_lean<H, NS, TAPER, INJ>(a, cs, xa, xe)) marchn<H, NS, false, 0, PF, false, 0, FDW_PIPE_ROWS, true>(a, lane, k, cs, xa, xe, link, fifo);
+        if (pipe_lean<H, NS, TAPER, INJ, DD>(a, cs, xa, xe)) {
+            if constexpr ((FDW_PIPE_OPT & 128) != 0 && !DD) {
+                if (k == 0) marchn<H, NS, false, 0, PF, DD, 0, FDW_PIPE_ROWS, true, 1>(a, lane, k, cs, xa, xe, link, fifo);
+                else marchn<H, NS, false, 0, PF, DD, 0, FDW_PIPE_ROWS, true, 2>(a, lane, k, cs, xa, xe, link, fifo);
+            } else {
+                marchn<H, NS, false, 0, PF, DD, 0, FDW_PIPE_ROWS, true>(a, lane, k, cs, xa, xe, link, fifo);
+            }
+        }
         else marchn<H, NS, TAPER, INJ, PF, DD, BK>(a, lane, k, cs, xa, xe, link, fifo);
     } else {
         marchn<H, NS, TAPER, INJ, PF, DD, BK>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo);
@@ -417,14 +450,30 @@ __global__ __launch_bounds__(128 * NS, 2) void fdw_back4_kernel(const Step2Args 
     __shared__ f4 fifo[kFusedFifoRows][64];
     __shared__ f4 imf[16][64];
     const int cs = zb * (64 - 2 * NS) - NS;
-    constexpr bool kLean = (FDW_PIPE_OPT & 32) != 0;
+    constexpr bool kLean = (FDW_PIPE_OPT & 32) != 0, kSplit = (FDW_PIPE_OPT & 256) != 0;
     if (k8 < NS) {
-        if (kLean && pipe_lean<H, NS, false, 0>(a, cs, xa, xe)) marchn<H, NS, false, 0, PF, false, 3, 1, true>(a, lane, k8, cs, xa, xe, linkF, fifo);
-        else marchn<H, NS, false, 0, PF, false, 3>(a, lane, k8, cs, xa, xe, linkF, fifo);
+        if (kLean && pipe_lean<H, NS, false, 0>(a, cs, xa, xe)) {
+            if constexpr (kSplit) {
+                if (k8 == 0) marchn<H, NS, false, 0, PF, false, 3, 1, true, 1>(a, lane, k8, cs, xa, xe, linkF, fifo);
+                else marchn<H, NS, false, 0, PF, false, 3, 1, true, 2>(a, lane, k8, cs, xa, xe, linkF, fifo);
+            } else {
+                marchn<H, NS, false, 0, PF, false, 3, 1, true>(a, lane, k8, cs, xa, xe, linkF, fifo);
+            }
+        } else {
+            marchn<H, NS, false, 0, PF, false, 3>(a, lane, k8, cs, xa, xe, linkF, fifo);
+        }
     } else {
         // receiver role: lean where the tile holds neither the damped strip nor the receiver line
-        if (kLean && pipe_lean<H, NS, true, 2>(a, cs, xa, xe)) marchn<H, NS, false, 0, PF, false, 4, 1, true>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
-        else marchn<H, NS, true, 2, PF, false, 4>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
+        if (kLean && pipe_lean<H, NS, true, 2>(a, cs, xa, xe)) {
+            if constexpr (kSplit) {
+                if (k8 == NS) marchn<H, NS, false, 0, PF, false, 4, 1, true, 1>(a, lane, 0, cs, xa, xe, linkR, fifo, imf, linkF);
+                else marchn<H, NS, false, 0, PF, false, 4, 1, true, 2>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
+            } else {
+                marchn<H, NS, false, 0, PF, false, 4, 1, true>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
+            }
+        } else {
+            marchn<H, NS, true, 2, PF, false, 4>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
+        }
     }
 }
 

@@ -592,6 +592,43 @@ def test_model_shot_vs_oracle_bit_exact(case):
             assert_bit_equal(ctx.model_shot(v2, sx0 + nxb, sz0 + nzb, gz0 + nzb, srce[:n]), want[:, :n], f"pipeline gather xchunk={xchunk} nt={n}")
 
 
+def test_model_steps_fields_vs_oracle_through_lean_and_full_tiles():
+    """The modelling loop on device arrays from random fields, compared FIELD by field (not only the gather): a grid wide and long enough
+    that the wave pipeline runs its lean body (no frame masks, no damping, no source, no trace) in the tiles away from the frame, the four
+    damped strips, the source blob and the receiver line, and the full body everywhere else.  The device arrays hold the fields before
+    the damping the loop applies to them afterwards (csrc/fdw_device.h, "lazy taper"): P one pass short, PP two."""
+    import torch
+    nx, nz, nxb, nzb, fac = 420, 688, 16, 16, 0.02
+    nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+    sx, sz, gz = 200, 452, 440                                 # blob across the border of z strips 1 and 2; receivers in strip 1
+    rng = np.random.default_rng(77)
+    v2 = ((1500 + 2500 * rng.random((nxe, nze))) ** 2).astype(np.float32)
+    P0 = (1e-3 * rng.standard_normal((nxe, nze))).astype(np.float32)
+    PP0 = (1e-3 * rng.standard_normal((nxe, nze))).astype(np.float32)
+    dev = torch.device("cuda:0")
+    for nsteps, xchunk in ((8, 43), (9, 0), (6, 61)):
+        srce = (1e-2 * rng.standard_normal(nsteps)).astype(np.float32)
+        ctx = F.FDWave(8, nxe, nze, nxb, nzb, nsteps, fac, 10.0, 12.5, 0.001, dialect=1)
+        ctx.set_tuning(two_step=4, xchunk=xchunk)
+        assert ctx.steps_per_pass() == 4
+
+        def up(a):
+            t = torch.zeros((nxe, ctx.pitch), device=dev)
+            t[:, :nze] = torch.from_numpy(a).to(dev)
+            return t
+        p, pp, dv2, dsr = up(P0), up(PP0), up(v2), torch.from_numpy(srce).to(dev)
+        rec = torch.zeros((nsteps, nx), device=dev)
+        torch.cuda.synchronize()
+        ctx.dev_model_steps(p.data_ptr(), pp.data_ptr(), dv2.data_ptr(), dsr.data_ptr(), sx, sz, gz, rec.data_ptr(), 0, nsteps)
+        torch.cuda.synchronize()
+        wP, wPP, wdata = O.mod_steps(8, nx, nz, nxb, nzb, 10.0, 12.5, 0.001, fac, v2, sx, sz, gz, srce,
+                                     O.mod_taper_apply(P0, nx, nz, nxb, nzb, fac, 1), O.mod_taper_apply(PP0, nx, nz, nxb, nzb, fac, 2))
+        assert_bit_equal(rec.cpu().numpy().T, wdata, f"gather nsteps={nsteps} xchunk={xchunk}")
+        gP, gPP = (p, pp) if nsteps % 2 == 0 else (pp, p)      # the two caller-owned arrays swap roles every step
+        assert_bit_equal(O.mod_taper_apply(gP[:, :nze].cpu().numpy(), nx, nz, nxb, nzb, fac, 1), wP, f"P nsteps={nsteps} xchunk={xchunk}")
+        assert_bit_equal(O.mod_taper_apply(gPP[:, :nze].cpu().numpy(), nx, nz, nxb, nzb, fac, 2), wPP, f"PP nsteps={nsteps} xchunk={xchunk}")
+
+
 def test_model_dialect_guards():
     ctx = F.FDWave(8, 80, 70, 10, 10, 10, 0.02, 10.0, 10.0, 0.001, dialect=1)
     v2 = np.full((80, 70), 4e6, np.float32)
