@@ -11,8 +11,8 @@
 //   * a wave marches along x over `xchunk` rows keeping the rows of p it needs in a REGISTER ring
 //     (2H+1 stencil rows + look-ahead rows that are still in flight), so x taps never touch memory
 //     twice inside a chunk and HBM latency is covered by explicit software prefetch, not occupancy;
-//   * z taps come from the two neighbouring lanes (ds_bpermute via __shfl_up/down by one lane; DPP
-//     wave shifts were measured 8 % slower on gfx950); the 4+4 halo columns of a strip come from ONE
+//   * z taps come from the two neighbouring lanes (DPP wave shifts, lane_up / lane_down below; the LDS crossbar that
+//     __shfl_up / __shfl_down compile to cost the pipeline kernel 4 %); the 4+4 halo columns of a strip come from ONE
 //     extra load issued by all lanes (lane 0 the left piece, every other lane the right piece);
 //   * taper, Laplacian, leap-frog update, point-source / receiver injection and the imaging
 //     condition are fused: p, pp, v2 are read once and pp written once = 16 B/point/step
@@ -168,6 +168,34 @@ __device__ __forceinline__ float leapfrog_pt(float p, float pp, float v2, float 
 #endif
     const double d = 2.0 * (double)p - (double)pp + (double)prod;
     return (float)d;
+}
+
+// The neighbouring lane's value through the VALU's DPP path (v_mov_b32_dpp wave_shr:1 / wave_shl:1) instead of the LDS crossbar
+// (ds_bpermute_b32, what __shfl_up / __shfl_down compile to).  Lane 0 (63) has no source and reads 0: both are halo lanes.
+template <int CTRL>
+__device__ __forceinline__ float lane_shift(float x)
+{
+    // bound_ctrl: the lane without a source reads 0, so the builtin's "old" operand is dead and costs no initialising v_mov
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+#ifndef FDW_DPP
+#define FDW_DPP 1          // 0: __shfl_up / __shfl_down (timing experiments)
+#endif
+__device__ __forceinline__ float lane_up(float x)
+{
+#if FDW_DPP
+    return lane_shift<0x138>(x);        // wave_shr:1 -- lane i takes lane i-1's
+#else
+    return __shfl_up(x, 1, 64);
+#endif
+}
+__device__ __forceinline__ float lane_down(float x)
+{
+#if FDW_DPP
+    return lane_shift<0x130>(x);        // wave_shl:1
+#else
+    return __shfl_down(x, 1, 64);
+#endif
 }
 
 // ---- packed fp32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE fp32 operations per lane and instruction) --------------

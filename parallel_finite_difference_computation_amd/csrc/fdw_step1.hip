@@ -197,7 +197,7 @@ __device__ __forceinline__ void march(const StepArgs& a, const ShotView& sv, con
                 lft.v[e] = c.v[e] + hal.v[e];
                 rgt.v[e] = c.v[e] - hal.v[e];
 #else
-                const float up = __shfl_up(c.v[e], 1, 64), dn = __shfl_down(c.v[e], 1, 64);
+                const float up = lane_up(c.v[e]), dn = lane_down(c.v[e]);
                 lft.v[e] = lane_first ? hal.v[e] : up;
                 rgt.v[e] = lane_last ? hal.v[e] : dn;
 #endif
@@ -274,7 +274,7 @@ __device__ __forceinline__ void march(const StepArgs& a, const ShotView& sv, con
                 f4 flft, frgt;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float up = __shfl_up(fc.v[e], 1, 64), dn = __shfl_down(fc.v[e], 1, 64);
+                    const float up = lane_up(fc.v[e]), dn = lane_down(fc.v[e]);
                     flft.v[e] = lane_first ? fhal.v[e] : up;
                     frgt.v[e] = lane_last ? fhal.v[e] : dn;
                 }
@@ -447,8 +447,8 @@ __global__ __launch_bounds__(256) void fdw_taper_finalize_kernel(float* f, const
 
 // ------------------------------------------------------------------------------------------------
 // device self test of the two hardware behaviours the kernels rely on:
-//   out[0..63]    = __shfl_up(src, 1)     (lane 0 keeps its own value)
-//   out[64..127]  = __shfl_down(src, 1)   (lane 63 keeps its own value)
+//   out[0..63]    = lane_up(src)     (lane i takes lane i-1's value; lane 0's result is unspecified)
+//   out[64..127]  = lane_down(src)   (lane i takes lane i+1's value; lane 63's result is unspecified)
 //   out[128..383] = a 64 x float4 row written with the range-predicated buffer store: lanes 2..61 store at
 //                   their own offset, the others at 0xFFFFFFF0 and must be dropped by the descriptor check
 // ------------------------------------------------------------------------------------------------
@@ -488,8 +488,8 @@ __global__ __launch_bounds__(256) void fdw_static_rows_kernel(float* pp, const f
 __global__ void fdw_selftest_kernel(const float* src, float* out)
 {
     const int t = threadIdx.x;
-    out[t] = __shfl_up(src[t], 1, 64);
-    out[64 + t] = __shfl_down(src[t], 1, 64);
+    out[t] = lane_up(src[t]);
+    out[64 + t] = lane_down(src[t]);
     f4 v;
     v.v[0] = v.v[1] = v.v[2] = v.v[3] = src[t];
     const unsigned off = (t >= 2 && t <= 61) ? (unsigned)t * 16u : 0xFFFFFFF0u;

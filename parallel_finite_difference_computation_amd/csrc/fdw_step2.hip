@@ -136,8 +136,8 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
             f4 lft, rgt;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                lft.v[e] = __shfl_up(c1.v[e], 1, 64);
-                rgt.v[e] = __shfl_down(c1.v[e], 1, 64);
+                lft.v[e] = lane_up(c1.v[e]);
+                rgt.v[e] = lane_down(c1.v[e]);
             }
             const bool rowok1 = (s >= a.lap_x0) && (s < a.lap_x1);
             const bool rowupd1 = (s >= 0) && (s < a.upd_x1);
@@ -179,8 +179,8 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
                 const f4 c2 = ring2[(U - H + R) % R];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    lft.v[e] = __shfl_up(c2.v[e], 1, 64);
-                    rgt.v[e] = __shfl_down(c2.v[e], 1, 64);
+                    lft.v[e] = lane_up(c2.v[e]);
+                    rgt.v[e] = lane_down(c2.v[e]);
                 }
                 const bool rowok2 = (r >= a.lap_x0) && (r < a.lap_x1);
                 f4 u2;

@@ -54,15 +54,6 @@ __device__ __forceinline__ int pipe_fifo_slot(int m)
 // wave 0 fills the shared v2 FIFO, every wave's new row also serves the receiver wave of its level), 4 = receiver field (one march step
 // behind: its rows, windows and FIFO slots are those of role 3 shifted by D = 1, so that the source-field row it images against was
 // written to the link buffers during the step before; v2 for all four waves from the FIFO; image as in BK 2)
-// The neighbouring lane's value through the VALU's DPP path (v_mov_b32_dpp wave_shr:1 / wave_shl:1) instead of the LDS crossbar
-// (ds_bpermute_b32, what __shfl_up / __shfl_down compile to).  Lane 0 (63) has no source and reads 0: both are halo lanes.
-template <int CTRL>
-__device__ __forceinline__ float lane_shift(float x)
-{
-    // bound_ctrl: the lane without a source reads 0, so the builtin's "old" operand is dead and costs no initialising v_mov
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
-}
-
 // LEAN: the body for workgroups that touch neither the frame of the grid (no Laplacian / update masks, no row clamps), nor the damped strip,
 // nor the source (instantiate with TAPER = false, INJ = 0): the kernel picks it per workgroup (pipe_lean)
 template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0, int ROWS = FDW_PIPE_ROWS, bool LEAN = false, int WK = 0>
