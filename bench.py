@@ -501,7 +501,22 @@ def run_rtm_slab_workload(args):
     if world > 1:
         dist.destroy_process_group()
     if not (finite and nonzero):
-        sys.exit("bench: image is not finite / all zero")
+        sys.exit(f"bench: image is not finite / all zero (finite {finite}, nonzero {nonzero})")
+
+
+def poison_free_memory():
+    """Development aid (FDW_BENCH_POISON=1): fill the free device memory with NaNs and release it again, so that anything the run reads
+    without having written it shows up as a NaN result instead of depending on what the previous process left behind."""
+    free, _ = torch.cuda.mem_get_info()
+    chunks = []
+    left = int(free * 0.9)
+    while left > (1 << 28):
+        nb = min(left, 8 << 30)
+        chunks.append(torch.full((nb // 4,), float("nan"), device="cuda"))
+        left -= nb
+    torch.cuda.synchronize()
+    del chunks
+    torch.cuda.empty_cache()
 
 
 def main():
@@ -525,6 +540,8 @@ def main():
     ap.add_argument("--init", choices=["noise", "rest"], default="noise",
                     help="initial wavefield: seeded noise (default; every cache line carries real data) or at rest (zeros + source)")
     args = ap.parse_args()
+    if os.environ.get("FDW_BENCH_POISON") == "1":
+        poison_free_memory()
     if args.workload == "rtm-slab":
         if not torch.cuda.is_available():
             sys.exit("bench: no GPU visible (the product has no CPU path)")

@@ -367,10 +367,18 @@ __device__ __forceinline__ f4 f4_load_arr(__amdgpu_buffer_rsrc_t rs, unsigned vo
     o.v[0] = r.x; o.v[1] = r.y; o.v[2] = r.z; o.v[3] = r.w;
     return o;
 }
+// HARDWARE HAZARD (gfx950, found in round 2 by scripts/stress_rtmslab.py): a buffer_store_dwordx4 whose soffset is an SGPR still reads its
+// data VGPRs during the next instruction slots; a VALU instruction that overwrites one of them straight after the store makes the store
+// write the NEW value (seen as a lane's byte offset landing in the wavefield, on some launches only).  hipcc pads that pair only for stores
+// WITHOUT a register soffset (GCNHazardRecognizer::createsVALUHazard).  The empty-bodied wait below reads the four data registers, so
+// every later write to them is at least two wait states behind the store.
 __device__ __forceinline__ void f4_store_arr(__amdgpu_buffer_rsrc_t rs, unsigned voff_bytes, unsigned row_off_bytes, const f4& a)
 {
     const v4f t = {a.v[0], a.v[1], a.v[2], a.v[3]};
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), rs, voff_bytes, row_off_bytes, (FDW_NT & 2) ? 2 : 0);
+#ifndef FDW_NO_STORE_PAD       // (defined only to show that tests/test_slabs_gpu.py::test_full_size_shot_is_reproducible... catches the hazard)
+    asm volatile("s_nop 1" : : "v"(t) : "memory");
+#endif
 }
 
 }  // namespace fdw

@@ -30,10 +30,11 @@ namespace fdw {
 #define FDW_DD_WG 4
 #endif
 #ifndef FDW_PIPE_OPT
-#define FDW_PIPE_OPT 481   // 1: waves skip the march steps outside their useful window; 4: the frame masks only in workgroups that touch the frame;
+#define FDW_PIPE_OPT 993   // 1: waves skip the march steps outside their useful window; 4: the frame masks only in workgroups that touch the frame;
                            // 32: workgroups away from the frame, the damped strip and the sources run the lean body (pipe_lean);
                            // 64: neighbouring lanes' values through DPP (v_mov_b32_dpp wave_shr / wave_shl) instead of ds_bpermute_b32;
-                           // 128 / 256: the lean body compiled once for wave 0 and once for the other waves (forward / fused backward kernel)
+                           // 128 / 256 / 512: the lean body compiled once for wave 0 and once for the other waves (forward kernel / source-field role / receiver
+                           // role of the fused backward kernel); 1024, 2048: experiments (one of the two only)
 #endif                     //    (measured slower: 581 vs 590 Gpoints/s at 8192^2)
 #ifndef FDW_PIPE_ROWS
 #define FDW_PIPE_ROWS 1    // march steps between two workgroup barriers of the pipeline kernel (1 or 2)
@@ -345,7 +346,14 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             f4_store_arr(rs_img, sim, rowoff(r), im);
         }
         // ---- look-ahead loads of wave 0 into the slots this step freed ----
+#ifdef FDW_WK2_KEEP_LOAD
+        ring[U] = load_p(b0 + m + R);
+#elif defined(FDW_WK2_ZERO)
         if constexpr (WK != 2) ring[U] = load_p(b0 + m + R);
+        else { ring[U].v[0] = ring[U].v[1] = ring[U].v[2] = ring[U].v[3] = 0.0f; }
+#else
+        if constexpr (WK != 2) ring[U] = load_p(b0 + m + R);
+#endif
         qpp[Q] = load_pw(rs_pp, s0 + m + PF);
         if constexpr (BK != 4) qv2[Q] = load_pw(rs_v2, s0 + m + PF);
         if constexpr (BK == 2) qlv[Q] = f4_load_arr(rs_lev, ioff, rowoff(r + PF), (FDW_NT & 1) != 0);
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(128 * NS, 2) void fdw_back4_kernel(const Step2Args 
     __shared__ f4 fifo[kFusedFifoRows][64];
     __shared__ f4 imf[16][64];
     const int cs = zb * (64 - 2 * NS) - NS;
-    constexpr bool kLean = (FDW_PIPE_OPT & 32) != 0, kSplit = (FDW_PIPE_OPT & 256) != 0;
+    constexpr bool kLean = (FDW_PIPE_OPT & 32) != 0, kSplit = (FDW_PIPE_OPT & 256) != 0, kSplitR = (FDW_PIPE_OPT & 512) != 0;
     if (k8 < NS) {
         if (kLean && pipe_lean<H, NS, false, 0>(a, cs, xa, xe)) {
             if constexpr (kSplit) {
@@ -456,8 +464,14 @@ __global__ __launch_bounds__(128 * NS, 2) void fdw_back4_kernel(const Step2Args 
     } else {
         // receiver role: lean where the tile holds neither the damped strip nor the receiver line
         if (kLean && pipe_lean<H, NS, true, 2>(a, cs, xa, xe)) {
-            if constexpr (kSplit) {
+            if constexpr (kSplitR) {
                 if (k8 == NS) marchn<H, NS, false, 0, PF, false, 4, 1, true, 1>(a, lane, 0, cs, xa, xe, linkR, fifo, imf, linkF);
+                else marchn<H, NS, false, 0, PF, false, 4, 1, true, 2>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
+            } else if constexpr ((FDW_PIPE_OPT & 1024) != 0) {
+                if (k8 == NS) marchn<H, NS, false, 0, PF, false, 4, 1, true, 1>(a, lane, 0, cs, xa, xe, linkR, fifo, imf, linkF);
+                else marchn<H, NS, false, 0, PF, false, 4, 1, true>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
+            } else if constexpr ((FDW_PIPE_OPT & 2048) != 0) {
+                if (k8 == NS) marchn<H, NS, false, 0, PF, false, 4, 1, true>(a, lane, 0, cs, xa, xe, linkR, fifo, imf, linkF);
                 else marchn<H, NS, false, 0, PF, false, 4, 1, true, 2>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
             } else {
                 marchn<H, NS, false, 0, PF, false, 4, 1, true>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);

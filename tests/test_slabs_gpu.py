@@ -157,3 +157,54 @@ def test_random_slab_decompositions_property(monkeypatch):
 
     check()
     assert {p for _, p in seen} == {True, False} and len({w for w, _ in seen}) >= 3
+
+
+def test_full_size_shot_is_reproducible_and_writes_nothing_it_did_not_compute():
+    """The bench's single-rank shot (8192^2, C slab driver: forward, hand-over, fused backward passes) repeated from the same start: fields
+    and image identical run to run, and the receiver field EXACTLY zero beyond the reach of the receiver line (4 columns per iteration).
+    This is the check that exposed the gfx950 store hazard (csrc/fdw_device.h, f4_store_arr): a buffer_store_dwordx4 with an SGPR soffset
+    followed by a VALU write of its data registers stored, on some launches, a lane's byte offset instead of the field value -- a
+    denormal-sized number that the oracle comparisons of short runs never met."""
+    import torch
+    n, nb, K = 8192, 64, 14                                  # 2 single iterations + 3 fused passes
+    dev = torch.device("cuda:0")
+    sl = F.Slabs(8, n, n, nb, nb, K, 0.75, 10.0, 10.0, 1e-3, comm=None, compat=False)
+    nfb, nrb = sl.back_buffers()
+    assert (nfb, nrb) == (6, 4), "the fused backward pipeline is expected to run at this size"
+    nsrc = max(sl.nbuf, nfb)
+    gz, nx = nb + 3, n - 2 * nb
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    srce = torch.from_numpy(F.ricker_wavelet(K, 1e-3, 20.0)).to(dev)
+    samples = torch.randn((K, nx), device=dev, generator=g)
+    noise = [1e-3 * torch.randn((n, n), device=dev, generator=g) for _ in range(2)]
+    fld = [torch.zeros((n, sl.pitch), device=dev) for _ in range(nsrc + nrb)]
+    v2 = torch.zeros((n, sl.pitch), device=dev)
+    v2[:, :n] = (1500.0 + 2500.0 * torch.rand((n, n), device=dev, generator=g)) ** 2
+    img = torch.zeros((n, sl.pitch), device=dev)
+    first = None
+    for rep in range(4):
+        for f in fld:
+            f.zero_()
+        fld[0][:, :n], fld[1][:, :n] = noise[0], noise[1]
+        img.zero_()
+        torch.cuda.synchronize()
+        ip, ipp = sl.dev_forward([f.data_ptr() for f in fld[:sl.nbuf]], v2.data_ptr(), srce.data_ptr(), n // 2, nb + 2, 0, K, True, 0, 1)
+        sl.taper_finalize(fld[ip].data_ptr())
+        rcv = fld[nsrc:]
+        role = sl.dev_back([f.data_ptr() for f in fld[:nsrc]], [r.data_ptr() for r in rcv], v2.data_ptr(), samples.data_ptr(), gz, img.data_ptr(), 0, K,
+                           role=(ip, ipp, 0, 1))
+        sl.synchronize()
+        torch.cuda.synchronize()
+        state = [img.clone(), fld[role[0]].clone(), fld[role[1]].clone(), rcv[role[2]].clone(), rcv[role[3]].clone()]
+        reach = gz + 4 * K + 4
+        for r_ in state[3:]:
+            assert float(r_[:, reach:].abs().max().item()) == 0.0, f"repetition {rep}: receiver field non-zero beyond column {reach}"
+        assert float(state[0][:, reach:n].abs().max().item()) == 0.0, f"repetition {rep}: image non-zero beyond column {reach}"
+        assert all(bool(torch.isfinite(t).all().item()) for t in state)
+        if first is None:
+            first = state
+        else:
+            for name, a, b in zip(("image", "F1", "F0", "R1", "R0"), state, first):
+                assert torch.equal(a, b), f"repetition {rep}: {name} differs from the first repetition in {int((a != b).sum().item())} cells"
+    sl.close()
