@@ -477,9 +477,31 @@ def run_rtm_slab_workload(args):
                 sys.exit("bench: the decomposed image differs from the single-domain image")
         else:
             dist.send(own, dst=0)
+    # N = 1 through the C driver: the dominant kernel is the fused backward pass (four iterations per launch); its launch time is measured
+    # here, on the slab's stream, as the difference of two backward loops that differ by 32 passes
+    back_launch_s = None
+    if world == 1 and c_driver and me["sl"].back_buffers() == (6, 4) and nt >= 2 + 4 * 40:
+        sl, fld, rcv = me["sl"], me["fld"], me["fld"][me["nsrc"]:]
+        ext = torch.cuda.ExternalStream(sl.stream)
+        scratch_img = torch.zeros_like(me["img"])
+
+        def back_ms(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(ext)
+            sl.dev_back([f_.data_ptr() for f_ in fld[:me["nsrc"]]], [r_.data_ptr() for r_ in rcv], me["v2"].data_ptr(), samples.data_ptr(), gz,
+                        scratch_img.data_ptr(), 0, iters, role=(me["ip"], me["ipp"], 0, 1))
+            e1.record(ext)
+            sl.synchronize()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1)
+        back_ms(2 + 4 * 8)
+        ts = sorted(back_ms(2 + 4 * 40) - back_ms(2 + 4 * 8) for _ in range(5))
+        back_launch_s = ts[len(ts) // 2] * 1e-3 / 32
     if rank == 0:
         upd = 3.0 * n * n * K
         bytes_min = (16.0 + 16.0 + 28.0) * n * n * K         # forward step 16 B/point + backward iteration 44 B/point (40 + the image read)
+        piped = c_driver and me["sl"].back_buffers() == (6, 4)
+        bytes_job = (20.0 / 4 + 44.0 / 4) * n * n * K if piped else bytes_min
         out = {"metric": "Gpoints/s (stencil updates) + achieved HBM GB/s vs peak", "value": round(upd / wall / 1e9, 3), "unit": "Gpoints/s", "n_gpus": world,
                "steps": K, "warmup": W, "ms_per_step": round(wall * 1e3 / K, 6), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic (seeded noise wavefield and gather)",
@@ -490,9 +512,34 @@ def run_rtm_slab_workload(args):
                "halo_exchange": ("RCCL ncclSend/ncclRecv groups issued by libfdwave.so on the communication stream" if c_driver else "torch.distributed gloo (single-GPU rehearsal harness)") if world > 1 else None,
                "decomposition_check": check,
                "timing": {"windows": nwin, "window_steps": K, "statistic": "median window (barrier + synchronize on both sides, max over ranks)"},
-               "roofline": {"bound": "hbm", "achieved": round(bytes_min / wall / 1e9, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                            "frac": round(bytes_min / wall / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None,
-                            "basis": "algorithmic bytes of the one-step kernels: forward step 16 B/point, backward iteration 44 B/point (two field updates + image), owned rows only"}}
+               "roofline": {"bound": "hbm", "achieved": round(bytes_job / wall / 1e9, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                            "frac": round(bytes_job / wall / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None,
+                            "basis": ("minimum bytes the job's launches must move per time index (" + ("four-step passes: forward 20 B/point per 4 steps, backward 44 B/point per "
+                                      "4 iterations" if piped else "one-step kernels: forward 16 B/point, backward iteration 44 B/point") + "; owned rows only) / wall time of the "
+                                      "median window, against N x the HBM peak"),
+                            "one_step_model": {"bytes": bytes_min, "achieved": round(bytes_min / wall / 1e9, 1),
+                                               "note": "SURVEY.md 8(d)'s byte model of the one-step kernels (16 + 44 B/point per time index): a throughput figure, NOT a roofline fraction"}}}
+        if back_launch_s:
+            prof = offline_counters("rtm-slab", n, 1)
+            traffic = prof["hbm_bytes_per_launch"] if prof else None
+            min_bytes = 44.0 * n * n                        # 6 fields in (F_k, F_k-1, r, r', v2, image) + 5 out per point and launch
+            basis = traffic if traffic else min_bytes
+            out["roofline"] = {"bound": "hbm", "achieved": round(basis / back_launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(basis / back_launch_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "basis": ("HBM-side bytes per launch measured with rocprofv3 --pmc (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) / launch time of this run"
+                                         if traffic else "minimum bytes one launch must move (six fields in, five out) / launch time of this run"),
+                               "traffic_source": (f"offline profile {prof.get('source')} taken on kernel sources {prof.get('source_hash')} (= this build)" if prof else
+                                                  "none: profiles/traffic.json holds no entry for this size / kernel build (a stale profile is never quoted)"),
+                               "kernel": "fdw::fdw_back4_kernel<4,4,2> (four backward iterations per launch: source-field and receiver-field pipelines of four waves each, imaging fused)",
+                               "launch_us": round(back_launch_s * 1e6, 2), "iterations_per_launch": 4, "min_bytes_per_launch": min_bytes,
+                               "min_bytes_frac": round(min_bytes / back_launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                               "algorithmic_44B_model": {"bytes_per_launch": 4 * 44.0 * n * n, "achieved": round(4 * 44.0 * n * n / back_launch_s / 1e9, 1),
+                                                         "ratio_to_peak": round(4 * 44.0 * n * n / back_launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                                                         "note": "SURVEY.md 8(d)'s one-pass-per-iteration byte model (44 B/point/iteration x 4); a throughput figure in bytes, NOT a roofline fraction"},
+                               "whole_shot_one_step_model": {"bytes": bytes_min, "achieved": round(bytes_min / wall / 1e9, 1),
+                                                             "note": "forward 16 + backward 44 B/point per time index over the wall time (the model of the one-step kernels)"}}
+            if prof and prof.get("valu_busy") is not None:
+                out["roofline"]["issue"] = {"valu_busy": prof["valu_busy"], "salu_per_valu": prof.get("salu_per_valu"), "source": prof.get("sq_source")}
         print(json.dumps(out), flush=True)
     if c_driver:
         me["sl"].close()
