@@ -1379,3 +1379,45 @@ def test_model_shot_batch_equals_the_shots_one_by_one(case):
             assert_bit_equal(got[b], want, f"shot {b}, nt {n}")
     b = nshots - 1
     assert_bit_equal(got[b], O.mod_shot(order, nx, nz, nxb, nzb, 10.0, 12.5, 0.001, 0.02, v2, sx0 + b * dsx, sz, gz, srce[:nt - 3]), "vs oracle")
+
+
+@pytest.mark.parametrize("which", ["forward", "model"])
+def test_long_full_size_runs_are_reproducible(which):
+    """A few hundred launches of the kernels bench.py times at 8192^2, repeated from the same start: bitwise identical every time.  The
+    oracle comparisons above run a handful of launches; a timing-dependent fault (the gfx950 store hazard of csrc/fdw_device.h,
+    f4_store_arr, showed on some launches only) needs many."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, nb, nt = 8192, 64, 160
+    dialect = 1 if which == "model" else 0
+    ctx = F.FDWave(8, n, n, nb, nb, nt, 0.75 if which == "forward" else 0.01, 10.0, 10.0, 0.001, compat=False, dialect=dialect)
+    pitch = ctx.pitch
+    assert ctx.steps_per_pass() == 4
+    g = torch.Generator(device=dev)
+    g.manual_seed(21)
+    init = [1e-3 * torch.randn((n, n), device=dev, generator=g) for _ in range(2)]
+    v2 = torch.zeros((n, pitch), device=dev)
+    v2[:, :n] = (1500.0 + 2500.0 * torch.rand((n, n), device=dev, generator=g)) ** 2
+    srce = torch.from_numpy((O.ricker_wavelet(nt, 0.001, 30.0) + 0.25).astype(np.float32)).to(dev)
+    first = None
+    for rep in range(3):
+        bufs = [torch.zeros((n, pitch), device=dev) for _ in range(4)]
+        bufs[0][:, :n], bufs[1][:, :n] = init[0], init[1]
+        rec = torch.zeros((nt, n - 2 * nb), device=dev)
+        torch.cuda.synchronize()
+        if which == "forward":
+            ip, ipp = ctx.dev_steps2([b.data_ptr() for b in bufs], v2.data_ptr(), srce.data_ptr(), n // 2, nb + 2, 0, nt, False, 0, 1)
+            torch.cuda.synchronize()          # the library enqueues on its own stream: wait before torch reads the arrays
+            state = [bufs[ip].clone(), bufs[ipp].clone()]
+        else:
+            ctx.dev_model_steps(bufs[0].data_ptr(), bufs[1].data_ptr(), v2.data_ptr(), srce.data_ptr(), n // 2, n // 2, nb, rec.data_ptr(), 0, nt)
+            torch.cuda.synchronize()
+            state = [bufs[0].clone(), bufs[1].clone(), rec.clone()]
+        torch.cuda.synchronize()
+        assert all(bool(torch.isfinite(t).all().item()) for t in state) and float(state[0].abs().max().item()) > 0
+        if first is None:
+            first = state
+        else:
+            for i, (a, b) in enumerate(zip(state, first)):
+                assert torch.equal(a, b), f"{which}: repetition {rep}, array {i} differs from the first repetition in {int((a != b).sum().item())} cells"
+        del bufs
