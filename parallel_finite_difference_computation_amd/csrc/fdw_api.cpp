@@ -716,7 +716,9 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
         // the eight-wave kernel holds two workgroups per CU (512 at a time): longer chunks than the forward kernel's at the same grid size
         // (scripts/probe_slabs_c.py, us per iteration by chunk length 43 / 83 / 123 / 173: 8192 rows 363 / 309 / 289 / 277; 4160 rows 192 / 172 / 157 / 162;
         //  2176 rows 109 / 94 / 102 / 93; 1152 rows 61 / 64 / 69 / 80)
-        xchunk = strip_rows >= 250000 ? 173 : (strip_rows >= 120000 ? 123 : (strip_rows >= 60000 ? 83 : 43));
+        // end of round 2 (lean bodies, scripts/probe_back.py, 8192 rows, us per iteration): 93: 240, 103: 233, 123: 228, 133: 230, 143: 234, 153: 226,
+        //  163: 234, 173: 234, 193: 233, 213: 225, 223: 231 -- 54 chunks x 37 strips fill the 512 workgroup slots 3.9 times over
+        xchunk = strip_rows >= 250000 ? 153 : (strip_rows >= 120000 ? 123 : (strip_rows >= 60000 ? 83 : 43));
         if (const char* e = getenv("FDW_BACK4_XCHUNK")) xchunk = atoi(e) > 0 ? atoi(e) : xchunk;      // experiments
     }
     if (rr.xchunk > 0) xchunk = rr.xchunk;
