@@ -6,6 +6,7 @@ argument meaning (extended-grid sizes, nz-before-nx order of the raw arrays, sx/
 extended grid).  All arrays are numpy float32 [nxe][nze] (x slow, z contiguous, fd-code.cu:58).
 """
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -123,6 +124,8 @@ class FDWave:
             self._h = C.c_void_p()
 
     def __del__(self):
+        if sys.is_finalizing():      # interpreter shutdown: the HIP runtime may already be gone, and the process frees everything anyway
+            return
         try:
             self.close()
         except Exception:

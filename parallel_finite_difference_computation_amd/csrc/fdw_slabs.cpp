@@ -358,10 +358,10 @@ extern "C" int fdw_slabs_dev_back(fdw_slabs* s, float* const* f, float* const* r
             if (i != rn && i != ro) { (q1 < 0 ? q1 : q2) = i; }
         }
     };
-    auto pass = [&](int a, int b, int a2, int b2, int xchunk) {
+    auto pass = [&](int a, int b, int a2, int b2, int xchunk, hipStream_t st) {
         if (a >= b && a2 >= b2) return (int)FDW_OK;
         return fdw_dev_back4(c, f[f1], f[f0], f[o1], f[o2], f[4], f[5], r[rn], r[ro], r[q1], r[q2], d_v2, d_samples + (size_t)it * nx, (int)nx, gz, d_img,
-                             it > 0, a, b, a2, b2, xchunk, s->compute);
+                             it > 0, a, b, a2, b2, xchunk, st);
     };
     const int cycle = s->world > 1 ? s->ksteps : (1 << 30);
     while (done < nsteps) {
@@ -385,7 +385,11 @@ extern "C" int fdw_slabs_dev_back(fdw_slabs* s, float* const* f, float* const* r
                     if (s->has_lo) { a0 = r0; a1 = lo_end; }
                     if (s->has_hi) { b0 = hi_beg; b1 = r1; }
                     if (!s->has_lo) { a0 = b0; a1 = b1; b0 = b1 = 0; }
-                    FDW_TRY(pass(a0, a1, b0, b1, 23));
+                    // the strips the neighbours need: a short latency chain on a stream of its own, beside the interior launch (disjoint rows of
+                    // the same output fields and of the image; the exchange waits for the side stream, the next cycle for the exchange)
+                    FDW_TRY(s->wait(s->side, s->compute));
+                    FDW_TRY(pass(a0, a1, b0, b1, 23, s->side));
+                    s->send_after = s->side;
                     nxt[0] = f[o2]; nxt[1] = f[o1]; nxt[2] = r[q2]; nxt[3] = r[q1];
                 } else {
                     FDW_TRY(iter(r0, lo_end));
@@ -393,10 +397,10 @@ extern "C" int fdw_slabs_dev_back(fdw_slabs* s, float* const* f, float* const* r
                     nxt[0] = it >= 2 ? f[f0] : f[f1]; nxt[1] = it >= 2 ? f[f1] : f[f0]; nxt[2] = r[ro]; nxt[3] = r[rn];      // the roles the next iteration sees
                 }
                 FDW_TRY(s->exchange(4, nxt));
-                if (four_now) FDW_TRY(pass(lo_end, hi_beg, 0, 0, 0));
+                if (four_now) FDW_TRY(pass(lo_end, hi_beg, 0, 0, 0, s->compute));
                 else FDW_TRY(iter(lo_end, hi_beg));
             } else {
-                if (four_now) FDW_TRY(pass(r0, r1, 0, 0, 0));
+                if (four_now) FDW_TRY(pass(r0, r1, 0, 0, 0, s->compute));
                 else FDW_TRY(iter(r0, r1));
             }
             if (four_now) {

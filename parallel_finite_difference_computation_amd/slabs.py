@@ -3,6 +3,7 @@ host threads of one process) and the forward / backward loops of rtm_code on one
 exchange over RCCL / xGMI inside the C library.  The reference has no multi-GPU path; the decomposed result is
 bit-identical to the single-domain one.  decomp.py holds the same scheme in Python as the test harness (gloo, CPU oracle stepper)."""
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -67,6 +68,8 @@ class Comm:
             self._h = C.c_void_p()
 
     def __del__(self):
+        if sys.is_finalizing():      # interpreter shutdown: the HIP runtime may already be gone, and the process frees everything anyway
+            return
         try:
             self.close()
         except Exception:
@@ -141,6 +144,8 @@ class Slabs:
             self._h = C.c_void_p()
 
     def __del__(self):
+        if sys.is_finalizing():      # interpreter shutdown: the HIP runtime may already be gone, and the process frees everything anyway
+            return
         try:
             self.close()
         except Exception:

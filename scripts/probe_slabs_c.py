@@ -46,12 +46,14 @@ def run(world, ksteps, back):
     tag = f"N={world} rows/rank={sl.own1 - sl.own0} nxl={sl.nxl} ksteps={sl.ksteps} nbuf={sl.nbuf}"
     print(f"{'backward' if back else 'forward '} {tag}: {best / steps * 1e6:8.1f} us/step  whole job {n * n * steps / best / 1e9:8.1f} Gpoints/s", flush=True)
     sl.close()
+    if comm is not None:
+        comm.close()
     return n * n * steps / best / 1e9
 
 
 for back in ((True,) if os.environ.get("ONLY_BACK") else (False, True)):
     base = run(1, 0, back)
     for world in (2, 4, 8):
-        for k in ((0,) if not back else (16,)):
+        for k in (tuple(int(x) for x in os.environ["KSTEPS"].split(",")) if os.environ.get("KSTEPS") else ((0,) if not back else (16,))):
             v = run(world, k, back)
             print(f"    -> {v / base:5.2f} x the one-GPU figure", flush=True)
