@@ -16,6 +16,10 @@ def timeit(fn, n=12, warm=3):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 cases = [((8192, 8192), (173, 123)), ((1152, 8192), (43, 33, 63)), ((4096, 4096), (83,)), ((16384, 16384), (253,))]
+if os.environ.get("PIPE_SHAPE"):        # e.g. PIPE_SHAPE=4128x8192 PIPE_CHUNKS=83,103,123
+    nx_, nz_ = (int(v) for v in os.environ["PIPE_SHAPE"].split("x"))
+    cases = [((nx_, nz_), (43, 83, 123, 173))]
+    sys.argv = sys.argv[:1]
 if os.environ.get("PIPE_CHUNKS"):
     cases = [(c[0], tuple(int(x) for x in os.environ["PIPE_CHUNKS"].split(","))) for c in cases]
 if len(sys.argv) > 1:
