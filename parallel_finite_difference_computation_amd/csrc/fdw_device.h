@@ -369,9 +369,9 @@ __device__ __forceinline__ f4 f4_load_arr(__amdgpu_buffer_rsrc_t rs, unsigned vo
 }
 // HARDWARE HAZARD (gfx950, found in round 2 by scripts/stress_rtmslab.py): a buffer_store_dwordx4 whose soffset is an SGPR still reads its
 // data VGPRs during the next instruction slots; a VALU instruction that overwrites one of them straight after the store makes the store
-// write the NEW value (seen as a lane's byte offset landing in the wavefield, on some launches only).  hipcc pads that pair only for stores
-// WITHOUT a register soffset (GCNHazardRecognizer::createsVALUHazard).  The empty-bodied wait below reads the four data registers, so
-// every later write to them is at least two wait states behind the store.
+// write the NEW value (seen as a lane's byte offset landing in the wavefield, on some launches only).  hipcc (ROCm 7.2) emitted the two
+// back to back (it seems to pad that pair only for stores without a register soffset).  The wait below takes the four data registers as
+// inputs, so every later write to them is at least two wait states behind the store.
 __device__ __forceinline__ void f4_store_arr(__amdgpu_buffer_rsrc_t rs, unsigned voff_bytes, unsigned row_off_bytes, const f4& a)
 {
     const v4f t = {a.v[0], a.v[1], a.v[2], a.v[3]};
