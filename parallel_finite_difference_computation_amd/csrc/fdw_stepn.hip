@@ -206,11 +206,14 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         if (act) {
         // pp and v2 of this row live in the look-ahead queue's registers: wave 0 finds them there (loaded PF steps ago), the other waves
         // read theirs from LDS into the same registers (their own look-ahead loads are switched off and return nothing they need)
-        f4 &ppt = qpp[Q], &v2t = qv2[Q];
+        f4 &ppt = qpp[Q], &v2t = qv2[Q];                        // v2t: v2 dt2 once past the block below
         if (first) {
             if constexpr (BK == 4) {
                 v2t = fifo[pipe_fifo_slot<FD>(m - D)][lane];     // the source-field role's wave 0 parked it one step ago
             } else {
+                // v2 dt2 (R:89's first product) is formed once, here, and travels through the FIFO in place of v2
+                const v2f w01 = v2f{qv2[Q].v[0], qv2[Q].v[1]} * a.dt2, w23 = v2f{qv2[Q].v[2], qv2[Q].v[3]} * a.dt2;
+                qv2[Q].v[0] = w01.x; qv2[Q].v[1] = w01.y; qv2[Q].v[2] = w23.x; qv2[Q].v[3] = w23.y;
 #if !(FDW_ABL_BITS & 128)
                 fifo[pipe_fifo_slot<FD>(m)][lane] = qv2[Q];
 #endif
@@ -258,7 +261,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
                 constexpr int P = decltype(PP)::value;
                 v2f lap2 = lapq[P];
                 if constexpr (!LEAN) lap2 = v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
-                const v2f prod2 = (f4_pair(v2t, P) * a.dt2) * lap2;
+                const v2f prod2 = f4_pair(v2t, P) * lap2;          // v2t holds v2 dt2 (see above)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int e = 2 * P + q;
@@ -275,7 +278,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
                 v2f lap2 = lapq[P];
                 if constexpr (!LEAN)
                     if (edge) lap2 = v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
-                const v2f prod2 = (f4_pair(v2t, P) * a.dt2) * lap2;
+                const v2f prod2 = f4_pair(v2t, P) * lap2;          // v2t holds v2 dt2 (see above)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int e = 2 * P + q;
