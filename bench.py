@@ -76,6 +76,11 @@ def offline_counters(workload, n, steps_per_launch):
     return None
 
 
+def traffic_source_note(prof):
+    return (f"offline profile {prof.get('source')} taken on kernel sources {prof.get('source_hash')} (= this build)" if prof else
+            "none: profiles/traffic.json holds no entry for this size / kernel build (a stale profile is never quoted)")
+
+
 def timed_windows(window, sync_all, world, dev, max_windows=400):
     """Times `window()` (EXACTLY K steps, enqueue only) bracketed by barrier + synchronize on both sides, max over ranks; repeats the window
     until MIN_TIMED_SECONDS have been measured and returns (median wall seconds, median device ms between HIP events, windows).  A 20-step
@@ -187,6 +192,7 @@ def run_model_workload(args):
            "timing": {"windows": nwin, "window_steps": K, "statistic": "median window"},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "basis": "measured HBM-side bytes per launch" if traffic else "minimum bytes one launch must move",
+                        "traffic_source": traffic_source_note(prof),
                         "kernel": "fdw::fdw_stepn_kernel<4,4,true,3,2,true> (four time steps per launch)" if spl == 4 else "fdw::fdw_step_kernel<4,true,3,false,false,2,true>",
                         "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": spl, "min_bytes_per_launch": min_bytes,
                         "algorithmic_16B_model": {"bytes_per_launch": algo, "achieved": round(algo / launch_s / 1e9, 1),
@@ -253,6 +259,7 @@ def run_stencil_workload(args):
            "result_finite_nonzero": finite, "timing": {"windows": nwin, "window_steps": K, "statistic": "median window"},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "basis": "measured HBM-side bytes per launch" if traffic else "algorithmic bytes: 8 B/point (read p, write lap)",
+                        "traffic_source": traffic_source_note(prof), "algorithmic_frac": round(algo / launch_s / 1e9 / HBM_PEAK_GBS, 4),
                         "kernel": "fdw::fdw_step_kernel<4,false,0,false,true,2> (Laplacian only)", "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": 1,
                         "algorithmic_bytes_per_launch": algo}}
     if not args.no_cpu_baseline:

@@ -544,3 +544,34 @@ def test_psnr_program_against_the_reference_tool(tmp_path):
         for k, v in zip(("mse", "rmse", "snr", "psnr"), ost):
             assert st[k] == v, (k, st[k], v)
             assert st2[k] == v or abs(st2[k] - v) <= 1e-4 * max(abs(v), 1.0), (k, st2[k], v)
+
+
+def test_committed_bench_lines_keep_the_contract():
+    """The bench lines committed under profiles/ (what DESIGN.md quotes) carry every field the driver's contract names, a roofline fraction that
+    is a fraction, and a traffic figure taken on the kernel build the profile names."""
+    import glob
+    import json
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+    files = sorted(glob.glob(os.path.join(root, "r02_bench_*.json")))
+    assert len(files) >= 6
+    for f in files:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert key in d, f"{os.path.basename(f)}: {key} missing"
+        assert d["unit"] == "Gpoints/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["n_gpus"] == 1
+        assert "workload" in d["config"] and "model" not in d["config"]
+        r = d["roofline"]
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert key in r, f"{os.path.basename(f)}: roofline.{key} missing"
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+        assert 0.0 < r["frac"] <= 1.0, f"{os.path.basename(f)}: roofline.frac = {r['frac']} is not a fraction"
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        if r["traffic"] is not None:
+            assert "profiles/" in r.get("traffic_source", ""), os.path.basename(f)
+        if "cpu_baseline" in d:
+            for key in ("value", "unit", "cores", "kind", "sample"):
+                assert key in d["cpu_baseline"], f"{os.path.basename(f)}: cpu_baseline.{key} missing"
+    entries = json.load(open(os.path.join(root, "traffic.json")))
+    assert {e["workload"] for e in entries} >= {"forward", "stencil", "rtm-slab", "model"}
+    for e in entries:
+        assert os.path.exists(os.path.join(root, "..", e["source"])), e["source"]
