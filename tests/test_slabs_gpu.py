@@ -208,3 +208,59 @@ def test_full_size_shot_is_reproducible_and_writes_nothing_it_did_not_compute():
             for name, a, b in zip(("image", "F1", "F0", "R1", "R0"), state, first):
                 assert torch.equal(a, b), f"repetition {rep}: {name} differs from the first repetition in {int((a != b).sum().item())} cells"
     sl.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_geometry_slabs_equal_the_single_domain(world):
+    """The decompositions bench.py --gpus 2 / 4 / 8 runs (8192^2, x-slabs of 4096 / 2048 / 1024 owned rows, 8 / 12 / 16 steps per exchange, four
+    steps per pass inside the slabs, strips on the side stream, lean and full tiles) with the ranks as host threads sharing this GPU and real halo copies: forward
+    loop, hand-over, backward loop with imaging on device arrays -- owned rows of both source fields, both receiver fields and the image
+    equal the single-domain run bit for bit."""
+    import torch
+    n, nb, K = 8192, 64, 40                                 # N = 8: two whole cycles of 16 + leftovers (forward: 8 steps; backward: 2 + 16 + 16 + 6)
+    dev = torch.device("cuda:0")
+    gz, nx = nb + 3, n - 2 * nb
+    g = torch.Generator(device=dev)
+    g.manual_seed(31)
+    srce = torch.from_numpy((F.ricker_wavelet(K, 1e-3, 20.0) + 0.25).astype(np.float32)).to(dev)
+    samples = torch.randn((K, nx), device=dev, generator=g)
+    noise = [1e-3 * torch.randn((n, n), device=dev, generator=g) for _ in range(2)]
+    v2g = (1500.0 + 2500.0 * torch.rand((n, n), device=dev, generator=g)) ** 2
+    torch.cuda.synchronize()
+
+    def shot(comm):
+        sl = F.Slabs(8, n, n, nb, nb, K, 0.75, 10.0, 10.0, 1e-3, comm=comm, compat=False)
+        nfb, nrb = sl.back_buffers()
+        assert (nfb, nrb) == (6, 4) and sl.nbuf == 4 and (comm is None or sl.ksteps == {2: 8, 4: 12, 8: 16}[world])
+        nsrc = max(sl.nbuf, nfb)
+        x0, nxl = sl.x_off, sl.nxl
+        fld = [torch.zeros((nxl, sl.pitch), device=dev) for _ in range(nsrc + nrb)]
+        fld[0][:, :n], fld[1][:, :n] = noise[0][x0:x0 + nxl], noise[1][x0:x0 + nxl]
+        v2 = torch.zeros((nxl, sl.pitch), device=dev)
+        v2[:, :n] = v2g[x0:x0 + nxl]
+        img = torch.zeros((nxl, sl.pitch), device=dev)
+        torch.cuda.synchronize()
+        ip, ipp = sl.dev_forward([f.data_ptr() for f in fld[:sl.nbuf]], v2.data_ptr(), srce.data_ptr(), n // 2 + 5, nb + 2, 0, K, True, 0, 1)
+        sl.taper_finalize(fld[ip].data_ptr())
+        rcv = fld[nsrc:]
+        role = sl.dev_back([f.data_ptr() for f in fld[:nsrc]], [r.data_ptr() for r in rcv], v2.data_ptr(), samples.data_ptr(), gz, img.data_ptr(), 0, K,
+                           role=(ip, ipp, 0, 1))
+        sl.synchronize()
+        torch.cuda.synchronize()
+        a, b = sl.own0 - x0, sl.own1 - x0
+        out = [t[a:b, :n].clone() for t in (img, fld[role[0]], fld[role[1]], rcv[role[2]], rcv[role[3]])]
+        own = (sl.own0, sl.own1)
+        sl.close()
+        return out, own
+
+    want, _ = shot(None)
+    comms = F.Comm.local(world)
+    res = F.run_ranks(lambda r: shot(comms[r]), world)
+    rows = 0
+    for out, (o0, o1) in res:
+        rows += o1 - o0
+        for name, got, ref in zip(("image", "F1", "F0", "R1", "R0"), out, want):
+            assert torch.equal(got, ref[o0:o1]), f"rows {o0}..{o1}: {name} differs from the single-domain run in {int((got != ref[o0:o1]).sum().item())} cells"
+    assert rows == n and float(want[0].abs().max().item()) > 0
+    for c in comms:
+        c.close()
