@@ -16,9 +16,11 @@ namespace fdw {
 // produced during step m-1 (its result row r_{k-1}(m-1) = r_k(m)+H, which enters wave k's window, and the
 // row its own window dropped, r_{k-1}(m-1)-H = r_k(m), which is wave k's "pp") is consumed during step m;
 // one workgroup barrier per march step separates producer and consumer, link buffers alternate by the parity
-// of m.  v2 rows ride a 16-row LDS FIFO filled by wave 0.  All waves run IDENTICAL code: the global loads of
-// waves k > 0 are sent out of range through the buffer descriptor (no memory request, zeros returned) and the
-// stores of waves < NS-2 likewise, so the s_waitcnt counting stays exact and nothing diverges.
+// of m.  v2 dt2 rows (formed once, by wave 0) ride a 16-row LDS FIFO.  In the FULL body all waves run identical code: the global loads of
+// waves k > 0 are sent out of range through the buffer descriptor (no memory request, zeros returned) and the stores of waves < NS-2
+// likewise, so the s_waitcnt counting stays exact and nothing diverges.  Workgroups away from the frame of the grid, the damped strip and
+// the sources -- nine in ten on a large grid -- run the LEAN body instead (pipe_lean: no masks, clamps, damping or injection code), which
+// is compiled once for wave 0 and once for the other waves (WK: no selects between "from memory" and "from LDS", no switched-off loads).
 // Validity: wave k's rows are good from march step k(2H+1) on (its window then holds only good rows of wave
 // k-1); in z every step costs H = one lane per side, so NS lanes per side of a wave are halo and 64-2NS owned.
 // Per point and step the arithmetic is the one-step kernel's (packed pairs as in the two-step kernel).
@@ -34,8 +36,8 @@ namespace fdw {
                            // 32: workgroups away from the frame, the damped strip and the sources run the lean body (pipe_lean);
                            // 64: neighbouring lanes' values through DPP (v_mov_b32_dpp wave_shr / wave_shl) instead of ds_bpermute_b32;
                            // 128 / 256 / 512: the lean body compiled once for wave 0 and once for the other waves (forward kernel / source-field role / receiver
-                           // role of the fused backward kernel); 1024, 2048: experiments (one of the two only)
-#endif                     //    (measured slower: 581 vs 590 Gpoints/s at 8192^2)
+                           // role of the fused backward kernel)
+#endif                     //    (bit 4 measured slower: 581 vs 590 Gpoints/s at 8192^2; bit 16: idle-step skipping for the modelling dialect, 5 % slower)
 #ifndef FDW_PIPE_ROWS
 #define FDW_PIPE_ROWS 1    // march steps between two workgroup barriers of the pipeline kernel (1 or 2)
 #endif
@@ -57,6 +59,7 @@ __device__ __forceinline__ int pipe_fifo_slot(int m)
 // written to the link buffers during the step before; v2 for all four waves from the FIFO; image as in BK 2)
 // LEAN: the body for workgroups that touch neither the frame of the grid (no Laplacian / update masks, no row clamps), nor the damped strip,
 // nor the source (instantiate with TAPER = false, INJ = 0): the kernel picks it per workgroup (pipe_lean)
+// WK: 0 = the wave finds out at run time whether it is wave 0 (full body); 1 / 2 = compiled for wave 0 / for the other waves (lean body)
 template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0, int ROWS = FDW_PIPE_ROWS, bool LEAN = false, int WK = 0>
 __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const int k, const int cs, const int xa, const int xe,
                                        f4 (*link)[2][2][ROWS][64], f4 (*fifo)[64], f4 (*imf)[64] = nullptr, f4 (*linkx)[2][2][ROWS][64] = nullptr)
@@ -349,14 +352,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             f4_store_arr(rs_img, sim, rowoff(r), im);
         }
         // ---- look-ahead loads of wave 0 into the slots this step freed ----
-#ifdef FDW_WK2_KEEP_LOAD
-        ring[U] = load_p(b0 + m + R);
-#elif defined(FDW_WK2_ZERO)
         if constexpr (WK != 2) ring[U] = load_p(b0 + m + R);
-        else { ring[U].v[0] = ring[U].v[1] = ring[U].v[2] = ring[U].v[3] = 0.0f; }
-#else
-        if constexpr (WK != 2) ring[U] = load_p(b0 + m + R);
-#endif
         qpp[Q] = load_pw(rs_pp, s0 + m + PF);
         if constexpr (BK != 4) qv2[Q] = load_pw(rs_v2, s0 + m + PF);
         if constexpr (BK == 2) qlv[Q] = f4_load_arr(rs_lev, ioff, rowoff(r + PF), (FDW_NT & 1) != 0);
@@ -469,12 +465,6 @@ __global__ __launch_bounds__(128 * NS, 2) void fdw_back4_kernel(const Step2Args 
         if (kLean && pipe_lean<H, NS, true, 2>(a, cs, xa, xe)) {
             if constexpr (kSplitR) {
                 if (k8 == NS) marchn<H, NS, false, 0, PF, false, 4, 1, true, 1>(a, lane, 0, cs, xa, xe, linkR, fifo, imf, linkF);
-                else marchn<H, NS, false, 0, PF, false, 4, 1, true, 2>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
-            } else if constexpr ((FDW_PIPE_OPT & 1024) != 0) {
-                if (k8 == NS) marchn<H, NS, false, 0, PF, false, 4, 1, true, 1>(a, lane, 0, cs, xa, xe, linkR, fifo, imf, linkF);
-                else marchn<H, NS, false, 0, PF, false, 4, 1, true>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
-            } else if constexpr ((FDW_PIPE_OPT & 2048) != 0) {
-                if (k8 == NS) marchn<H, NS, false, 0, PF, false, 4, 1, true>(a, lane, 0, cs, xa, xe, linkR, fifo, imf, linkF);
                 else marchn<H, NS, false, 0, PF, false, 4, 1, true, 2>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
             } else {
                 marchn<H, NS, false, 0, PF, false, 4, 1, true>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
