@@ -575,3 +575,20 @@ def test_committed_bench_lines_keep_the_contract():
     assert {e["workload"] for e in entries} >= {"forward", "stencil", "rtm-slab", "model"}
     for e in entries:
         assert os.path.exists(os.path.join(root, "..", e["source"])), e["source"]
+
+
+def test_built_library_has_no_store_followed_by_a_write_of_its_data():
+    """scripts/lint_store_hazard.py on the built libfdwave.so: no buffer_store_dwordx3/x4 with a register soffset is followed within two wait
+    states by a VALU write of its data registers (the gfx950 hazard of csrc/fdw_device.h, f4_store_arr; the check reads the disassembly
+    of the embedded gfx950 code objects, so it needs the ROCm tools but no GPU)."""
+    import importlib.util
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    lib = os.path.join(root, "parallel_finite_difference_computation_amd", "libfdwave.so")
+    if not (os.path.exists(lib) and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump")):
+        pytest.skip("needs the built library and the ROCm LLVM tools")
+    spec = importlib.util.spec_from_file_location("lint_store_hazard", os.path.join(root, "scripts", "lint_store_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    findings, nstores, nsymbols = mod.check(lib)
+    assert nsymbols > 20 and nstores >= 100, "the disassembly was not read (no kernels / no pipeline stores found)"
+    assert not findings, "\n".join(findings)
