@@ -53,7 +53,7 @@ def run(world, ksteps, back):
 
 for back in ((True,) if os.environ.get("ONLY_BACK") else (False, True)):
     base = run(1, 0, back)
-    for world in (2, 4, 8):
+    for world in (tuple(int(x) for x in os.environ["ONLY_WORLD"].split(",")) if os.environ.get("ONLY_WORLD") else (2, 4, 8)):
         for k in (tuple(int(x) for x in os.environ["KSTEPS"].split(",")) if os.environ.get("KSTEPS") else ((0,) if not back else (16,))):
             v = run(world, k, back)
             print(f"    -> {v / base:5.2f} x the one-GPU figure", flush=True)
