@@ -40,7 +40,7 @@ def main():
     wkey = head[head.index("--workload-key") + 1] if "--workload-key" in head else "forward"
     out = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     os.makedirs(out, exist_ok=True)
-    cmd_tail = ["--", "python3", os.path.join(ROOT, "bench.py")] + bench_args + ["--no-cpu-baseline"]
+    cmd_tail = ["--", "python3", os.path.join(ROOT, "bench.py")] + bench_args + ["--no-cpu-baseline", "--no-rest-line"]
     env = dict(os.environ, TMPDIR="/tmp")
 
     def run(name, args):
@@ -76,7 +76,7 @@ def main():
         if ln.startswith("{") and '"metric"' in ln:
             bench_line = json.loads(ln)
     from bench import kernel_source_hash
-    lines = [f"command: python3 bench.py {' '.join(bench_args)} --no-cpu-baseline   (kernel sources {kernel_source_hash(wkey)})", ""]
+    lines = [f"command: python3 bench.py {' '.join(bench_args)} --no-cpu-baseline --no-rest-line   (kernel sources {kernel_source_hash(wkey)})", ""]
     entry = None
     for kname in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", [0, 1])[0]):
         c = {k: v[0] / v[1] for k, v in agg[kname].items()}
