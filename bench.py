@@ -81,6 +81,38 @@ def traffic_source_note(prof):
             "none: profiles/traffic.json holds no entry for this size / kernel build (a stale profile is never quoted)")
 
 
+def reference_sibling_cpu(m, nti):
+    """The reference's OWN CPU path for this stencil -- fd.c / ptsrc.c / taper.c of dpct_gpu_rtm_domain_division/src, compiled unmodified into
+    oracle/_ref/libref_dd.so -- driven through mod_main's loop (mod_main.cpp:147-164: fd_step, ptsrc, taper_apply(PP), taper_apply(P), swap) on an
+    m x m grid for nti steps, one thread.  None when that library was not built (reference tree absent at build time)."""
+    import ctypes as C
+    from oracle import oracle as O
+    R = O.ref_dd_lib()
+    if R is None:
+        return None
+    fp = C.POINTER(C.c_float)
+    hv2 = np.full((m, m), 2500.0 ** 2, np.float32)
+    hs = F.mod_ricker_wavelet(nti, DT, FPEAK)
+    P, PP = np.zeros((m, m), np.float32), np.zeros((m, m), np.float32)
+    rows = lambda a: (fp * a.shape[0])(*[C.cast(a[i].ctypes.data, fp) for i in range(a.shape[0])])
+    rP, rPP, rV = rows(P), rows(PP), rows(hv2)
+    R._Z7fd_initiiifff(ORDER, m, m, C.c_float(DX), C.c_float(DX), C.c_float(DT))
+    R._Z10taper_initiif(NB, NB, C.c_float(0.01))
+    t0 = time.perf_counter()
+    for it in range(nti):
+        R._Z7fd_stepiPPfS0_S0_ii(ORDER, rP, rPP, rV, m, m)
+        R._Z5ptsrciiiifPPf(m // 2, m // 2, m, m, C.c_float(float(hs[it])), rPP)
+        R._Z11taper_applyPPfiiii(rPP, m - 2 * NB, m - 2 * NB, NB, NB)
+        R._Z11taper_applyPPfiiii(rP, m - 2 * NB, m - 2 * NB, NB, NB)
+        rP, rPP = rPP, rP
+    dt = time.perf_counter() - t0
+    R._Z10fd_destroyv()
+    R._Z13taper_destroyv()
+    return {"value": round(m * m * nti / dt / 1e9, 4), "unit": "Gpoints/s", "cores": 1, "kind": "reference",
+            "sample": f"{m}x{m} fp32 grid, {nti} steps of mod_main's loop through the reference's own fd_step / ptsrc / taper_apply "
+                      f"(dpct_gpu_rtm_domain_division/src, g++ -O3 as its Makefiles build them: oracle/_ref/libref_dd.so), single thread, {dt:.1f} s"}
+
+
 def timed_windows(window, sync_all, world, dev, max_windows=400):
     """Times `window()` (EXACTLY K steps, enqueue only) bracketed by barrier + synchronize on both sides, max over ranks; repeats the window
     until MIN_TIMED_SECONDS have been measured and returns (median wall seconds, median device ms between HIP events, windows).  A 20-step
@@ -200,15 +232,19 @@ def run_model_workload(args):
                                                   "note": "SURVEY.md 8(d)'s one-pass-per-step byte model; can exceed 1 for a temporally blocked launch -- not a roofline fraction"}}}
     if not args.no_cpu_baseline:
         from oracle import oracle as O
-        m = min(n, 2048)                       # bounded sample: the oracle's mod loop (with its own allocation and tables) on an m x m grid
-        nti = 400                              # ~10 s of one core
+        m = min(n, 2048)                       # bounded sample on an m x m grid
         hv2 = np.full((m, m), 2500.0 ** 2, np.float32)
-        hs = F.mod_ricker_wavelet(nti, DT, FPEAK)
-        t0 = time.perf_counter()
-        O.mod_shot(ORDER, m - 2 * NB, m - 2 * NB, NB, NB, DX, DX, DT, 0.01, hv2, m // 2, m // 2, NB, hs)
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(m * m * nti / dt / 1e9, 4), "unit": "Gpoints/s", "cores": 1, "kind": "port",
-                               "sample": f"{m}x{m} fp32 grid, {nti} steps of oracle/fdw_oracle_mod.c orc_mod_shot (gcc -O2 -ffp-contract=off), single thread, {dt:.1f} s"}
+        ref = reference_sibling_cpu(m, 200)
+        if ref is not None:
+            out["cpu_baseline"] = ref
+        else:
+            nti = 400                              # ~10 s of one core
+            hs = F.mod_ricker_wavelet(nti, DT, FPEAK)
+            t0 = time.perf_counter()
+            O.mod_shot(ORDER, m - 2 * NB, m - 2 * NB, NB, NB, DX, DX, DT, 0.01, hv2, m // 2, m // 2, NB, hs)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(m * m * nti / dt / 1e9, 4), "unit": "Gpoints/s", "cores": 1, "kind": "port",
+                                   "sample": f"{m}x{m} fp32 grid, {nti} steps of oracle/fdw_oracle_mod.c orc_mod_shot (gcc -O2 -ffp-contract=off), single thread, {dt:.1f} s"}
     print(json.dumps(out), flush=True)
     if not finite:
         sys.exit("bench: result is not finite / all zero")
@@ -922,6 +958,9 @@ def main():
                                             "note": "SQ counters: the kernel saturates the vector issue slots well below the HBM line; see DESIGN.md section 4"}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(n)
+                sib = reference_sibling_cpu(min(n, 2048), 100)      # the reference's own CPU code for the same stencil (its two-pass fd_step), beside our port
+                if sib is not None:
+                    out["cpu_baseline"]["reference_cpu_sibling"] = sib
         else:
             passes_bytes = (MIN_BYTES_PER_POINT_PER_LAUNCH / 4.0 if use_pipe else ALGO_BYTES_PER_POINT) * n * n * K      # whole job, ghost rows not counted
             algo = ALGO_BYTES_PER_POINT * n * n * K
