@@ -1421,3 +1421,46 @@ def test_long_full_size_runs_are_reproducible(which):
             for i, (a, b) in enumerate(zip(state, first)):
                 assert torch.equal(a, b), f"{which}: repetition {rep}, array {i} differs from the first repetition in {int((a != b).sum().item())} cells"
         del bufs
+
+
+def test_random_mid_size_decks_through_the_wave_pipeline_property():
+    """Property test over decks large enough for the wave pipeline's LEAN tiles (several 256-column strips, several chunks between the frame
+    rows) and small enough for the oracle: ragged extents, borders from 0 up, truncated or full launch extents, chunk lengths down to 13
+    rows, the source in a lean or in a full tile, receivers anywhere, dx != dz; the forward loop, the fused backward passes (iterations
+    beyond the two snapshots) and the image against the oracle, bit for bit."""
+    rng = np.random.default_rng(2026)
+    ncases = int(os.environ.get("FDW_PROPERTY_EXAMPLES", "16"))
+    lean_possible = 0
+    for case in range(ncases):
+        nxb, nzb = int(rng.integers(0, 41)), int(rng.integers(0, 41))
+        nx, nz = int(rng.integers(150, 620)), int(rng.integers(560, 1500))
+        compat = bool(rng.integers(0, 2))
+        nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+        xlim, zlim = (8 * (nxe // 8), 8 * (nze // 8)) if compat else (nxe, nze)
+        if compat and nxb + nx > xlim:      # receiver rows beyond the time-stepped rows: the backward pipeline steps aside (covered elsewhere)
+            nxb = max(nxb, 8)
+            nxe = nx + 2 * nxb
+            xlim = 8 * (nxe // 8)
+        nt = int(rng.integers(7, 15))
+        xchunk = int(rng.choice([0, 13, 23, 43, 63]))
+        sx = int(rng.integers(nxb, min(nxb + nx, xlim)))
+        sz = int(rng.integers(max(nzb, 4), min(nzb + nz, zlim)))
+        gz = int(rng.integers(nzb, nzb + nz))
+        dx, dz = [(10.0, 10.0), (25.0, 8.0), (8.0, 12.5)][int(rng.integers(0, 3))]
+        fac = float(rng.choice([0.3, 0.75, 1.0]))
+        d = make_deck(nxe, nze, nxb, nzb, nt, seed=1000 + case, order=8, compat=compat, fac=fac, dx=dx, dz=dz)
+        srce = (O.ricker_wavelet(nt, d["dt"], 30.0) + 0.5).astype(np.float32)
+        d_obs = np.random.default_rng(case).standard_normal((nx, nt)).astype(np.float32)
+        im0 = np.random.default_rng(case + 1).standard_normal((nx, nz)).astype(np.float32)
+        ctx, orc = mk(d), mko(d)
+        ctx.set_tuning(two_step=4, xchunk=xchunk)
+        assert ctx.steps_per_pass() == 4
+        what = f"case {case}: {nxe}x{nze} borders {nxb}/{nzb} compat {compat} nt {nt} xchunk {xchunk} source ({sx},{sz}) gz {gz} dx {dx} dz {dz}"
+        img, P, PP = ctx.shot(d["v2"], sx, sz, gz, srce, d_obs, imloc=im0, want_fields=True)
+        oP, oPP = orc.forward(d["v2"], sx, sz, srce)
+        oimg = orc.back(d["v2"], oP, oPP, d_obs, gz, imloc=im0)
+        assert_bit_equal(P, oP, f"P, {what}")
+        assert_bit_equal(PP, oPP, f"PP, {what}")
+        assert_bit_equal(img, oimg, f"image, {what}")
+        lean_possible += int(nze >= 2 * 256 + 64 and nxe >= 3 * max(xchunk, 43) + 100)
+    assert lean_possible >= ncases // 2
