@@ -264,3 +264,36 @@ def test_bench_geometry_slabs_equal_the_single_domain(world):
     assert rows == n and float(want[0].abs().max().item()) > 0
     for c in comms:
         c.close()
+
+
+@pytest.mark.parametrize("world,k,shape,compat", [(2, 8, (1310, 1207), False), (3, 4, (1533, 1641), True), (3, 8, (1999, 911), False), (4, 4, (1702, 1380), True)],
+                         ids=["2ranks-k8", "3ranks-k4-compat", "3ranks-k8", "4ranks-k4-compat"])
+def test_mid_size_slabs_with_lean_tiles_equal_the_single_domain(world, k, shape, compat, monkeypatch):
+    """Slabs a few hundred rows tall and several 256-column strips wide: the wave pipeline inside them runs lean tiles in the middle and
+    full tiles along the frame, the ghost bands and the split boundary strips, on ragged extents with dx != dz.  Image, P and PP gathered
+    from the ranks (threads on this GPU, real halo copies) equal fdw_shot on the whole grid bit for bit."""
+    nxe, nze = shape
+    nt = 2 * k + 2 * 4 + 3                                   # two whole cycles, one more pass, leftovers
+    d, srce, d_obs, im0 = _case(nxe, nze, 24, nt, compat, seed=world * 100 + k, dx=25.0, dz=8.0)
+    want, P, PP = _single(d, srce, d_obs, im0)
+    monkeypatch.setenv("FDW_SLAB_PIPE", "1")
+    comms = F.Comm.local(world)
+
+    def rank(r):
+        s = F.Slabs(d["order"], nxe, nze, d["nxb"], d["nzb"], nt, d["fac"], d["dx"], d["dz"], d["dt"], comm=comms[r], compat=compat, ksteps=k)
+        assert s.nbuf == 4 and s.back_buffers() == (6, 4)
+        out = s.shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs, imloc=im0, want_fields=True)
+        geo = (s.own0, s.own1, s.owned_interior_rows())
+        s.close()
+        return out, geo
+
+    res = F.run_ranks(rank, world)
+    img, gP, gPP = np.array(im0), np.zeros_like(P), np.zeros_like(PP)
+    for (im, p, pp), (o0, o1, (a, b)) in res:
+        img[a:b] = im[a:b]
+        gP[o0:o1], gPP[o0:o1] = p[o0:o1], pp[o0:o1]
+    for cm in comms:
+        cm.close()
+    assert_bit_equal(gPP, PP, "PP gathered from the ranks")
+    assert_bit_equal(gP, P, "P gathered from the ranks")
+    assert_bit_equal(img, want, "image gathered from the ranks")
