@@ -73,3 +73,22 @@ def random_fields(deck, seed, amp=1.0):
         p[xlim:, :ztap] = 0
         pp[xlim:, :ztap] = 0
     return p, pp
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _poison_free_device_memory():
+    """FDW_TEST_POISON=1: before the first test, fill the free device memory with NaNs and release it, so that anything a kernel reads without
+    it having been written shows up as a NaN mismatch instead of depending on what earlier processes left in HBM (development aid)."""
+    if os.environ.get("FDW_TEST_POISON") == "1":
+        import torch
+        if torch.cuda.is_available():
+            free, _ = torch.cuda.mem_get_info()
+            left, chunks = int(free * 0.9), []
+            while left > (1 << 28):
+                nb = min(left, 8 << 30)
+                chunks.append(torch.full((nb // 4,), float("nan"), device="cuda"))
+                left -= nb
+            torch.cuda.synchronize()
+            del chunks
+            torch.cuda.empty_cache()
+    yield
