@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""A new_mod-sized shot (415 x 295, nt = 1700) through fdw_forward / fdw_back with the one-step, two-step and pipeline kernels forced in turn:
+which kernel the launch-bound small-deck regime wants (development tool; the one-step kernel: 8.3 + 10.2 ms, two-step 16 + 29, pipeline 28 + 46)."""
 import sys, os, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import parallel_finite_difference_computation_amd as F
 nxe, nze, nb, nt = 415, 295, 40, 1700
