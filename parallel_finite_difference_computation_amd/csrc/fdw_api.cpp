@@ -362,7 +362,7 @@ static void fill_geometry(const fdw_ctx* c, StepArgs& a, int rows, int batch = 1
 
 static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const float* d_v2, int r0, int r1,
                      int pp_twice, const float* d_inj, int inj_x_global, int inj_z, const float* d_psrc, float* d_img,
-                     hipStream_t s, float* d_rec_row = nullptr, int rec_z = 0, float* d_fpp = nullptr)
+                     hipStream_t s, float* d_rec_row = nullptr, int rec_z = 0, float* d_fpp = nullptr, float* d_out = nullptr)
 {
     const bool lap = (mode == FDW_MODE_LAP);
     if (!d_p || !d_pp) return fail(FDW_EINVAL, "step: field pointer is NULL");
@@ -378,6 +378,7 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
 
     StepArgs a{};
     a.p = d_p; a.pp = d_pp; a.v2 = d_v2; a.psrc = d_psrc; a.img = d_img; a.fpp = d_fpp;
+    a.out = d_out;            // NULL: in place over pp
     a.taperz = c->d_taperz; a.txfac = c->d_txfac; a.inj = d_inj; a.gcx = c->d_gcx; a.gcz = c->d_gcz;
     a.pitch = c->pitch; a.nxl = c->nxl;
     a.r0 = r0;
@@ -1313,12 +1314,16 @@ extern "C" int fdw_rtm_stored_shot(fdw_ctx* c, const float* vel2, int sx, int sz
     float *d_p = c->fld[0], *d_pp = c->fld[1];
     HIP_TRY(hipMemsetAsync(d_p, 0, fe * sizeof(float), c->stream));     // rtm_main.cpp:161-162
     HIP_TRY(hipMemsetAsync(d_pp, 0, fe * sizeof(float), c->stream));
+    // The fields of the forward loop LIVE in the store: swf[it] = P of step it (rtm_main.cpp:177-181; an interior point is never damped, and the
+    // kernels damp on load), so step it reads p = swf[it], pp = swf[it-1] and writes the new field straight into swf[it+1] -- no copy per step
+    // (round 1 copied a whole field per step: 21 % of the device time of a 3lay_mod-sized shot).  P of step 0 and its predecessor are zero.
+    if (nt > 0) HIP_TRY(hipMemsetAsync(d_swf, 0, fe * (size_t)nt * sizeof(float), c->stream));      // step 0's P, and the padding columns of every slot
     for (int it = 0; it < nt; it++) {
-        rc = step_impl(c, FDW_MODE_DD_FWD, d_p, d_pp, c->d_v2, 0, c->nxl, 1, c->d_srce + it, sx, sz, nullptr, nullptr, c->stream);
+        const float* p_in = d_swf + (size_t)it * fe;
+        float* pp_in = it > 0 ? d_swf + (size_t)(it - 1) * fe : d_pp;                  // only read (out is given)
+        float* out = it + 1 < nt ? d_swf + (size_t)(it + 1) * fe : d_p;                // the last new field is not stored by the reference either
+        rc = step_impl(c, FDW_MODE_DD_FWD, p_in, pp_in, c->d_v2, 0, c->nxl, 1, c->d_srce + it, sx, sz, nullptr, nullptr, c->stream, nullptr, 0, nullptr, out);
         if (rc) return rc;
-        // swf[it] = P (rtm_main.cpp:177-181): the step leaves its p input untouched, and an interior point is never damped
-        HIP_TRY(hipMemcpyAsync(d_swf + (size_t)it * fe, d_p, fe * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-        std::swap(d_p, d_pp);
     }
     HIP_TRY(hipMemsetAsync(d_p, 0, fe * sizeof(float), c->stream));     // rtm_main.cpp:187-189
     HIP_TRY(hipMemsetAsync(d_pp, 0, fe * sizeof(float), c->stream));

@@ -25,6 +25,7 @@ constexpr int kMaxPipeSteps = 4;       // time levels of one pass of the wave-pi
 struct StepArgs {
     const float* p;        // [nxl][pitch] newest field (read only in this launch)
     float* pp;             // [nxl][pitch] older field, overwritten with the new one (or Laplacian out)
+    float* out;            // NULL, or where the new field goes INSTEAD of over pp (pp is then only read: stored-wavefield loops keep every field)
     const float* v2;       // [nxl][pitch] squared velocity
     const float* psrc;     // IMG: source wavefield to correlate with; BACK: F_{k-1}, the newer source field (read only)
     float* fpp;            // BACK: F_{k-2}, overwritten with the reconstructed F_k

@@ -29,6 +29,7 @@ namespace fdw {
 struct ShotView {
     const float* p;
     float* pp;
+    float* out;            // where the new field is stored: pp itself unless StepArgs::out names another array
     const float* v2;
     const float* psrc;
     float* fpp;
@@ -306,11 +307,11 @@ __device__ __forceinline__ void march(const StepArgs& a, const ShotView& sv, con
             if (res.v[0] == 123.456f)
 #endif
             if (!partial) {
-                f4_store(sv.pp + (size_t)r * pitch, voff, res);
+                f4_store(sv.out + (size_t)r * pitch, voff, res);
                 if constexpr (IMG) f4_store(sv.img + (size_t)r * pitch, voff, imr);
                 if constexpr (BACK) f4_store(sv.fpp + (size_t)r * pitch, voff, fres);
             } else if (act) {
-                f4_store(sv.pp + (size_t)r * pitch, voff, res);
+                f4_store(sv.out + (size_t)r * pitch, voff, res);
                 if constexpr (IMG) f4_store(sv.img + (size_t)r * pitch, voff, imr);
                 if constexpr (BACK) f4_store(sv.fpp + (size_t)r * pitch, voff, fres);
             }
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void fdw_step_kernel(const StepArgs a)
     // a batch of independent shots of one geometry fills the chip where one small grid cannot: blockIdx.y picks the shot
     const int shot = blockIdx.y;
     const long long o = shot * a.bstride;
-    const ShotView sv{a.p + o, a.pp + o, a.v2 + shot * a.v2_bstride, a.psrc + o, a.fpp + o, a.img + o, a.inj + shot * a.inj_bstride,
+    const ShotView sv{a.p + o, a.pp + o, (a.out ? a.out : a.pp) + o, a.v2 + shot * a.v2_bstride, a.psrc + o, a.fpp + o, a.img + o, a.inj + shot * a.inj_bstride,
                       a.inj_x + shot * a.inj_dx, a.rec + shot * a.rec_bstride};
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
