@@ -6,9 +6,14 @@ grid, device resident.  One JSON line on rank 0.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size 8192] [--ksteps 4] [--no-cpu-baseline]
 
 N = 1 : the whole grid on one MI355X.
-N > 1 : launched by torch.distributed.run, one rank per GPU; the SAME grid is split into x slabs with
-        deep-halo exchange over RCCL (parallel_finite_difference_computation_amd/decomp.py) -- strong
-        scaling, as BASELINE.json's "RTM domain decomposition, 8192^2 grid, 2->4->8" config asks.
+N > 1 : one rank per GPU; the SAME grid is split into x slabs with deep-halo exchange over RCCL inside
+        libfdwave.so (csrc/fdw_slabs.cpp, csrc/fdw_comm.cpp) -- strong scaling, as BASELINE.json's
+        "RTM domain decomposition, 8192^2 grid, 2->4->8" config asks.  `python bench.py --gpus N` starts its
+        N ranks itself (child processes, before anything touches HIP: self_launch below); launched by
+        `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it uses the ranks it is given.
+        The line then carries rccl_ranks (world size the communicator reports), halo_exchange (the path
+        the halo rows took) and exposed_comm_fraction (the same window re-timed with the transfers
+        switched off: 1 - t_stub / t).
 
 Metric: Gpoints/s = nxe*nze*K / wall (barrier + synchronize on both sides, max over ranks).
 Timing: the K-step window (barrier + synchronize on both sides) is repeated until 0.3 s have been measured; the MEDIAN window is
@@ -25,10 +30,74 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _gpus_on_command_line(argv):
+    """--gpus N / --gpus=N as the driver passes it (parsed by hand: nothing heavier than the standard library is imported yet)."""
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    return n
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one (fresh interpreters, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set as torch.distributed.run would) and wait for them.  This runs before torch or libfdwave.so is imported, so the
+    parent never touches HIP; nothing is exec'ed over a process that has.  Rank 0 inherits this process's stdout, so its JSON line is the last
+    line this command prints; the other ranks' stdout goes to stderr.  A rank that fails takes the others down (they would wait in a barrier
+    for ever); exit status = the first non-zero one."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    limit = float(os.environ.get("FDW_BENCH_LAUNCH_TIMEOUT", "1500"))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FDW_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr, start_new_session=True))
+    t0, rc, failed_at = time.time(), 0, None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and failed_at is None:
+            failed_at, rc = time.time(), bad[0].returncode
+        late = time.time() - t0 > limit
+        if late or (failed_at is not None and time.time() - failed_at > 15.0):
+            for p in procs:                      # exactly the processes started above, by PID (their own sessions: nothing else is signalled)
+                if p.poll() is None:
+                    try:
+                        os.killpg(p.pid, signal.SIGKILL)
+                    except OSError:
+                        pass
+            if late and rc == 0:
+                rc = 124
+                print(f"[bench] self-launch: the {n} ranks did not finish within {limit:.0f} s; killed", file=sys.stderr, flush=True)
+            break
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            pass
+    for p in procs:
+        if rc == 0 and p.returncode not in (0, None):
+            rc = p.returncode
+    return rc if rc >= 0 else 128 - rc
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and _gpus_on_command_line(sys.argv[1:]) > 1:
+    sys.exit(self_launch(_gpus_on_command_line(sys.argv[1:])))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
 sys.path.insert(0, ROOT)
 
 import parallel_finite_difference_computation_amd as F  # noqa: E402
@@ -44,6 +113,7 @@ MIN_TIMED_SECONDS = 0.3       # the K-step window is repeated until this much ti
 
 KERNEL_SOURCES = {      # the translation units behind each workload's dominant kernel (+ the shared device header and argument structs)
     "forward": ("fdw_stepn.hip", "fdw_step2.hip", "fdw_device.h", "fdw_kernels.h"),
+    "forward-fast": ("fdw_stepn.hip", "fdw_step2.hip", "fdw_device.h", "fdw_kernels.h"),      # the same sources, NUM = 1 instantiations (--numerics fast)
     "model": ("fdw_stepn.hip", "fdw_device.h", "fdw_kernels.h"),
     "rtm-slab": ("fdw_stepn.hip", "fdw_device.h", "fdw_kernels.h"),
     "stencil": ("fdw_step1.hip", "fdw_device.h", "fdw_kernels.h"),
@@ -137,6 +207,18 @@ def timed_windows(window, sync_all, world, dev, max_windows=400):
         if total >= MIN_TIMED_SECONDS or len(walls) >= max_windows:
             break
     return float(np.median(walls)), float(np.median(devs)), len(walls)
+
+
+def shm_communicator(rank, world, local_rank, n):
+    """--backend shm: this rank of the library's process transport (fdw_comm_init_shm).  The segment is named after the rendezvous port, which
+    every rank of this run shares and no other run does; a box holds the largest message: four fields x 64 ghost rows (16 steps per exchange)."""
+    name = f"/fdw_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}"
+    return F.Comm.shm(name, rank, world, local_rank, box_bytes=4 * 64 * ((n + 63) // 64 * 64) * 4)
+
+
+HALO_PATHS = {"rccl": "RCCL ncclSend/ncclRecv groups issued by libfdwave.so on the communication stream",
+              "shm": "libfdwave.so's process transport (fdw_comm_init_shm): halo blocks staged through shared memory, ranks may share a GPU -- a rehearsal, not xGMI",
+              "local": "device copies between ranks-as-threads inside libfdwave.so"}
 
 
 def synthetic_velocity_rows(n, row0, rows, device):
@@ -397,7 +479,7 @@ def run_rtm_slab_workload(args):
     nx = n - 2 * NB
     gz = NB + 3
     sx, sz = n // 2, NB + 2
-    c_driver = args.backend == "nccl"
+    c_driver = args.backend in ("nccl", "shm")
     mk = dict(compat=False)
     srce = torch.from_numpy(F.ricker_wavelet(nt, DT, FPEAK)).to(dev)
     gsmp = torch.Generator(device=dev)
@@ -464,7 +546,9 @@ def run_rtm_slab_workload(args):
         torch.cuda.synchronize()
 
     comm = None
-    if c_driver and world > 1:
+    if c_driver and world > 1 and args.backend == "shm":
+        comm = shm_communicator(rank, world, local_rank, n)
+    elif c_driver and world > 1:
         uid = [F.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         comm = F.Comm.rccl(uid[0], rank, world, local_rank)
@@ -520,6 +604,16 @@ def run_rtm_slab_workload(args):
             check_failed = not same        # the line is still printed (flagged), the exit code says so at the end
         else:
             dist.send(own, dst=0)
+    exposed = None
+    if c_driver and world > 1 and not args.no_exposed:
+        me["sl"].set_stub(True)            # the same shots with the transfers switched off; results are wrong from here on
+        shot(me, K)
+        sync(me)
+        wall_stub, _, _ = timed_windows(window, sync_all, world, dev, max_windows=max(2, nwin // 4))
+        me["sl"].set_stub(False)
+        exposed = {"value": round(max(0.0, 1.0 - wall_stub / wall), 4), "ms_per_step_with_transfers": round(wall * 1e3 / K, 6),
+                   "ms_per_step_transfers_off": round(wall_stub * 1e3 / K, 6),
+                   "method": "median window re-timed with fdw_slabs_set_stub(1): exchanges enqueue nothing, everything else unchanged"}
     # N = 1 through the C driver: the dominant kernel is the fused backward pass (four iterations per launch); its launch time is measured
     # here, on the slab's stream, as the difference of two backward loops that differ by 32 passes
     back_launch_s = None
@@ -552,8 +646,11 @@ def run_rtm_slab_workload(args):
                                       f"with imaging, {me['g'].ksteps if world > 1 else 0} steps per halo exchange", "grid": [n, n], "order": ORDER,
                           "parallelism": f"slab{world}" if world > 1 else "single"},
                "result_finite_nonzero": finite and nonzero,
-               "halo_exchange": ("RCCL ncclSend/ncclRecv groups issued by libfdwave.so on the communication stream" if c_driver else "torch.distributed gloo (single-GPU rehearsal harness)") if world > 1 else None,
+               "halo_exchange": (HALO_PATHS[comm.kind] if c_driver else "torch.distributed gloo (single-GPU rehearsal harness)") if world > 1 else None,
                "decomposition_check": check,
+               "rccl_ranks": comm.world if (comm is not None and comm.kind == "rccl") else None, "comm_ranks": comm.world if comm is not None else world,
+               "exposed_comm_fraction": exposed["value"] if exposed else None, "exposed_comm": exposed,
+               "launched_by": "bench.py itself (child processes)" if os.environ.get("FDW_BENCH_SELF_LAUNCHED") else ("an external launcher (torch.distributed.run)" if world > 1 else None),
                "timing": {"windows": nwin, "window_steps": K, "statistic": "median window (barrier + synchronize on both sides, max over ranks)"},
                "roofline": {"bound": "hbm", "achieved": round(bytes_job / wall / 1e9, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                             "frac": round(bytes_job / wall / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None,
@@ -626,10 +723,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rest-line", action="store_true", help="forward workload, N = 1: skip the extra measurement from BASELINE.md's zero initial fields")
     ap.add_argument("--no-overlap", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="N > 1: nccl = halo exchange over RCCL inside libfdwave.so, one rank per GPU (default); "
-                                                      "gloo = the Python harness over torch.distributed gloo, ranks may share one GPU (rehearsals)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "shm", "gloo"),
+                    help="N > 1: nccl = halo exchange over RCCL inside libfdwave.so, one rank per GPU (default); shm = the same C drivers over the "
+                         "library's process transport (shared-memory staging), ranks may share one GPU (rehearsals); gloo = the Python test harness")
     ap.add_argument("--check", action="store_true", help="N > 1: compare the decomposed result with a single-domain run on rank 0 (default with --backend nccl)")
     ap.add_argument("--no-check", action="store_true", help="N > 1, --backend nccl: skip that comparison")
+    ap.add_argument("--no-exposed", action="store_true", help="N > 1, --backend nccl: skip the re-timing with the transfers off (exposed_comm_fraction)")
+    ap.add_argument("--numerics", choices=["exact", "fast"], default="exact",
+                    help="exact (default, what `value` always reports in the default run): the reference's arithmetic operation for operation, bit-identical "
+                         "to the oracle; fast: fdw_params.numerics = FDW_NUMERICS_FAST (symmetric sums + fused multiply-adds in the Laplacian, within "
+                         "1e-5 of exact) for the whole run -- profiling and scaling runs of that mode; the default run prints it beside the headline")
+    ap.add_argument("--no-fast-line", action="store_true", help="forward workload, N = 1: skip the extra measurement in FAST numerics")
     ap.add_argument("--init", choices=["noise", "rest"], default="noise",
                     help="initial wavefield: seeded noise (default; every cache line carries real data) or at rest (zeros + source)")
     args = ap.parse_args()
@@ -663,15 +767,17 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane (barriers, the max over ranks of the window time, gathering the slabs for the check): a gloo group on the host.
-        # The data plane -- the halo rows -- travels inside libfdwave.so over RCCL / xGMI (--backend nccl, the default) or, for rehearsals
-        # of several ranks on ONE GPU (--backend gloo; RCCL refuses duplicate devices), through the Python harness decomp.SlabForward.
+        # The data plane -- the halo rows -- travels inside libfdwave.so: over RCCL / xGMI (--backend nccl, the default, one rank per GPU) or,
+        # for rehearsals of several ranks on ONE GPU (RCCL refuses duplicate devices), through the library's process transport (--backend shm:
+        # the same C drivers, halo blocks staged through shared memory).  --backend gloo runs the Python test harness instead.
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n, K, W = args.size, args.steps, args.warmup
     nt = K + W
+    NUM = 1 if args.numerics == "fast" else 0
     srce = torch.from_numpy(F.ricker_wavelet(nt, DT, FPEAK)).to(dev)
     sx, sz = n // 2, n // 2
-    c_driver = (world > 1 and args.backend == "nccl") or os.environ.get("FDW_FORCE_SLAB_DRIVER") == "c"      # the latter: the multi-GPU code path on one rank (tests)
+    c_driver = (world > 1 and args.backend in ("nccl", "shm")) or os.environ.get("FDW_FORCE_SLAB_DRIVER") == "c"      # the latter: the multi-GPU code path on one rank (tests)
     slabs = comm = harness_group = None
     use_pipe = False
     if c_driver:
@@ -680,21 +786,24 @@ def main():
         # -- together -- to the Python harness over torch.distributed's own RCCL group rather than lose the measurement.
         err = None
         uid = [None]
-        if rank == 0:
-            try:
-                uid = [F.Comm.unique_id()]
-            except F.FdwError as e:
-                err = e
-        if world > 1:
-            dist.broadcast_object_list(uid, src=0)
-        if uid[0] is not None:
-            try:
-                comm = F.Comm.rccl(uid[0], rank, world, local_rank)
-                comm.selftest()
-            except F.FdwError as e:
-                err = e
+        if args.backend == "shm" and world > 1:
+            comm = shm_communicator(rank, world, local_rank, n)
         else:
-            err = err or RuntimeError("rank 0 could not create the RCCL unique id")
+            if rank == 0:
+                try:
+                    uid = [F.Comm.unique_id()]
+                except F.FdwError as e:
+                    err = e
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            if uid[0] is not None:
+                try:
+                    comm = F.Comm.rccl(uid[0], rank, world, local_rank)
+                    comm.selftest()
+                except F.FdwError as e:
+                    err = e
+            else:
+                err = err or RuntimeError("rank 0 could not create the RCCL unique id")
         bad = torch.tensor([1.0 if err is not None else 0.0])
         if world > 1:
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)
@@ -710,7 +819,7 @@ def main():
             os.environ["FDW_SLAB_PIPE"] = "1" if args.pipe == "on" else "0"
         if args.no_overlap:
             os.environ["FDW_SLAB_NO_OVERLAP"] = "1"
-        slabs = F.Slabs(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, comm=comm, compat=False, ksteps=args.ksteps)
+        slabs = F.Slabs(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, comm=comm, compat=False, ksteps=args.ksteps, numerics=NUM)
         args.ksteps, use_pipe = slabs.ksteps, slabs.nbuf == 4
         geom = SlabGeometry(rank, world, n, ORDER // 2, slabs.ksteps)
         assert (geom.x_off, geom.nxl, geom.o0, geom.o1) == (slabs.x_off, slabs.nxl, slabs.own0, slabs.own1)
@@ -723,14 +832,14 @@ def main():
             args.ksteps = int(max(2, min(16, -(-500.0 // t_step_us))))
         if world > 1 and args.pipe != "off":
             # decide on the slab size every rank has in common (all ranks must take the same path): rows of the thinnest slab
-            probe = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank, slab=(0, n // world))
+            probe = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank, slab=(0, n // world), numerics=NUM)
             use_pipe = args.pipe == "on" or probe.steps_per_pass() == 4
             del probe
             if use_pipe:
                 args.ksteps = max(4, min(16, 4 * -(-args.ksteps // 4)))      # whole passes of four steps
         geom = SlabGeometry(rank, world, n, ORDER // 2, args.ksteps if world > 1 else 1)
         ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank,
-                       slab=(geom.x_off, geom.nxl) if world > 1 else None)
+                       slab=(geom.x_off, geom.nxl) if world > 1 else None, numerics=NUM)
         if os.environ.get("FDW_XCHUNK"):      # tuning experiments only
             ctx.set_tuning(xchunk=int(os.environ["FDW_XCHUNK"]))
         pitch = ctx.pitch
@@ -754,7 +863,7 @@ def main():
                 f_[:, :n] = full_rows[geom.x_off:geom.x_off + geom.nxl].repeat(1, n // 64)
         return fl
 
-    rest_line = None
+    rest_line = fast_line = None
     if world == 1 and not c_driver and not os.environ.get("FDW_FORCE_SLAB_DRIVER"):
         # One GPU: the library's forward loop over four rotating buffers (fdw_dev_steps2): pairs of time steps go
         # through the two-step kernel (temporal blocking) where it pays, everything enqueued by ONE library call.
@@ -820,6 +929,62 @@ def main():
             rest_line = {"init": "rest: zero fields + Ricker source at the grid centre (BASELINE.md section 4), steps 0 .. K-1", "value": round(n * n * K / (r_dev_ms * 1e-3) / 1e9, 3),
                          "unit": "Gpoints/s", "ms_per_step": round(r_dev_ms / K, 6), "windows": r_nwin,
                          "timing": "HIP events around the K enqueued steps (the fills between windows are outside them)"}
+        if NUM == 0 and not args.no_fast_line:
+            # The same K steps from the same noise start in FAST numerics (include/fdwave.h: symmetric sums + fused multiply-adds in the Laplacian,
+            # <= 1e-5 from the exact arithmetic -- tests/test_fast_numerics.py), beside the headline: `value` stays the exact mode's.
+            fctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank, numerics=1)
+            g = torch.Generator(device=dev)
+
+            def refill():
+                for b_ in bufs:
+                    b_.zero_()
+                if args.init == "noise":
+                    g.manual_seed(0x5EED0001)
+                    for b_ in bufs[:2]:
+                        b_[:, :n] = 1e-3 * torch.randn((n, n), device=dev, generator=g)
+                roles["ip"], roles["ipp"] = 0, 1
+                torch.cuda.synchronize()
+
+            def frun(it0, nsteps):
+                roles["ip"], roles["ipp"] = fctx.dev_steps2(ptrs, v2.data_ptr(), srce.data_ptr(), sx, sz, it0, nsteps, it0 > 0,
+                                                            roles["ip"], roles["ipp"], stream=stream.cuda_stream)
+
+            refill()
+            frun(0, W)
+            stream.synchronize()
+
+            def window_fast():
+                e0.record(stream)
+                frun(W, K)
+                e1.record(stream)
+                while not e1.query():
+                    pass
+                stream.synchronize()
+                return e0.elapsed_time(e1)
+
+            f_wall, f_dev_ms, f_nwin = timed_windows(window_fast, sync_all, world, dev)
+            f_new = bufs[roles["ipp"]]
+            f_ok = bool(torch.isfinite(f_new).all().item()) and float(f_new.abs().max().item()) > 0.0
+            f_spl = fctx.steps_per_pass()
+            f_rem = K % f_spl
+            f_launches = K // f_spl + (f_rem // 2 + f_rem % 2 if fctx.two_step_active() else f_rem)
+            f_launch_s = f_dev_ms * 1e-3 / f_launches
+            f_prof = offline_counters("forward-fast", n, f_spl)
+            f_traffic = f_prof["hbm_bytes_per_launch"] if f_prof else None
+            f_min = (ALGO_BYTES_PER_POINT if f_spl == 1 else MIN_BYTES_PER_POINT_PER_LAUNCH) * n * n
+            f_basis = f_traffic if f_traffic else f_min
+            fast_line = {"numerics": "FAST (fdw_params.numerics = 1): Laplacian as symmetric sums + fused multiply-adds, fp64 leap-frog kept; <= 1e-5 max-norm-relative "
+                                     "from the exact arithmetic over 1 700 steps (tests/test_fast_numerics.py)",
+                         "value": round(n * n * K / f_wall / 1e9, 3), "unit": "Gpoints/s", "ms_per_step": round(f_wall * 1e3 / K, 6), "windows": f_nwin,
+                         "result_finite_nonzero": f_ok,
+                         "roofline": {"bound": "hbm", "achieved": round(f_basis / f_launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(f_basis / f_launch_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": f_traffic,
+                                      "basis": "measured HBM-side bytes per launch" if f_traffic else "minimum bytes one launch must move",
+                                      "traffic_source": traffic_source_note(f_prof), "launch_us": round(f_launch_s * 1e6, 2), "steps_per_launch": f_spl,
+                                      "kernel": "fdw::fdw_stepn_kernel<4,4,true,1,2,false,0,1> (NUM = 1)" if f_spl == 4 else "FAST instantiation of the kernel above"}}
+            if f_prof and f_prof.get("valu_busy") is not None:
+                fast_line["roofline"]["issue"] = {"valu_busy": f_prof["valu_busy"], "salu_per_valu": f_prof.get("salu_per_valu"), "source": f_prof.get("sq_source")}
+            del fctx
     elif c_driver:
         # N GPUs, one rank each: the whole K-step window -- passes, boundary strips, halo exchange over RCCL on the communication stream,
         # interior rows beside the transfer -- is enqueued by ONE call into the C library (fdw_slabs_dev_forward)
@@ -870,7 +1035,7 @@ def main():
 
     check = None
     check_failed = False
-    if world > 1 and (args.check or (args.backend == "nccl" and not args.no_check)):
+    if world > 1 and (args.check or (args.backend in ("nccl", "shm") and not args.no_check)):
         # the decomposed field against a single-domain run of the same step sequence (warm-up, then `nwin` windows that replay the
         # source samples W .. W+K-1) on rank 0, bitwise: a halo that arrives late or not at all cannot hide behind a plausible number
         own = newest[:, :n].contiguous().cpu()
@@ -881,7 +1046,7 @@ def main():
             for r in range(1, world):
                 dist.recv(parts[r], src=r)
             full = torch.cat(parts).to(dev)
-            ref_ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank)
+            ref_ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank, numerics=NUM)
             rb = [torch.zeros((n, ref_ctx.pitch), device=dev) for _ in range(4)]
             if args.init == "noise":
                 g = torch.Generator(device=dev)
@@ -902,6 +1067,18 @@ def main():
             check_failed = not same        # the line is still printed (flagged), the exit code says so at the end
         else:
             dist.send(own, dst=0)
+    exposed = None
+    if c_driver and world > 1 and not args.no_exposed:
+        # the same window with the transfers switched off (launches and stream hand-overs stay): what the exchange costs the cycle.
+        # Results are wrong from here on, so this comes after `newest` and the check.
+        slabs.set_stub(True)
+        run(W, K)
+        slabs.synchronize()
+        wall_stub, _, _ = timed_windows(window, sync_all, world, dev, max_windows=max(3, nwin // 4))
+        slabs.set_stub(False)
+        exposed = {"value": round(max(0.0, 1.0 - wall_stub / wall), 4), "ms_per_step_with_transfers": round(wall * 1e3 / K, 6),
+                   "ms_per_step_transfers_off": round(wall_stub * 1e3 / K, 6),
+                   "method": "median window re-timed with fdw_slabs_set_stub(1): exchanges enqueue nothing, everything else unchanged"}
     if rank == 0:
         gpts = n * n * K / wall / 1e9
         # dominant kernel: the fused step.  At N = 1 one launch updates the whole grid; its average
@@ -919,12 +1096,22 @@ def main():
             "result_finite_nonzero": finite,
         }
         if world > 1:
-            out["halo_exchange"] = ("RCCL ncclSend/ncclRecv groups issued by libfdwave.so on the communication stream" if c_driver
+            out["halo_exchange"] = (HALO_PATHS[comm.kind] if c_driver
                                     else ("torch.distributed nccl P2P (fallback harness: RCCL was not usable from libfdwave.so)" if harness_group is not None
                                           else f"torch.distributed {args.backend} (single-GPU rehearsal harness)"))
             out["decomposition_check"] = check
+            out["rccl_ranks"] = comm.world if (c_driver and comm is not None and comm.kind == "rccl") else None
+            out["comm_ranks"] = comm.world if (c_driver and comm is not None) else world
+            out["exposed_comm_fraction"] = exposed["value"] if exposed else None
+            out["exposed_comm"] = exposed
+            out["launched_by"] = "bench.py itself (child processes)" if os.environ.get("FDW_BENCH_SELF_LAUNCHED") else "an external launcher (torch.distributed.run)"
         if rest_line is not None:
             out["baseline_md_initial_condition"] = rest_line
+        if fast_line is not None:
+            out["fast_numerics"] = fast_line
+        out["numerics"] = "fast" if NUM else "exact"
+        if NUM:
+            out["config"]["workload"] += ", FAST numerics (symmetric sums + fused multiply-adds in the Laplacian; <= 1e-5 from the reference's arithmetic)"
         out["timing"] = {"windows": nwin, "window_steps": K, "statistic": "median window (each bracketed by barrier + synchronize, max over ranks)",
                          "measured_seconds_min": MIN_TIMED_SECONDS}
         model_note = ("SURVEY.md 8(d)'s one-pass-per-step byte model (16 B/point/step x the steps one launch advances); a temporally blocked launch "

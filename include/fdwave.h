@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FDW_VERSION 1
+#define FDW_VERSION 2
 #define FDW_MAX_ORDER 32
 
 /* error codes */
@@ -60,7 +60,16 @@ typedef struct fdw_params {
                        1 (FDW_DIALECT_MOD): the CPU-serial sibling's forward modelling -- dpct_gpu_rtm_domain_division/src:
                        fd_step's single accumulator (timestep/fd.c:24-46), four-sided taper_apply with taper = exp(-(F*(nb-i))^2)
                        (boundary/taper.c:26-66), whole-grid update; order <= 8; only fdw_model_shot and the host helpers use it */
+    int numerics;   /* 0 (FDW_NUMERICS_EXACT, the default of a zeroed struct): the reference's arithmetic operation for operation (nvcc
+                       --fmad=false: every product and every sum of the Laplacian rounded, R:66-72) -- results identical to the no-FMA
+                       CUDA build bit for bit;
+                       1 (FDW_NUMERICS_FAST): the same stencil with the symmetric taps summed first and fused multiply-adds,
+                       lap = c0 p + sum_k [cz_k (p(j-k) + p(j+k)) + cx_k (p(i-k) + p(i+k))] (csrc/fdw_device.h), about half the vector
+                       instructions; the fp64 leap-frog (R:89), the taper, the launch extents and every other quirk are unchanged.
+                       Results agree with EXACT to rounding: <= 1e-5 max-norm-relative over the 1 700 steps of the reference's new_mod
+                       deck (tests), the size of the reference's own FMA / no-FMA difference.  RTM dialect only. */
 } fdw_params;
+enum { FDW_NUMERICS_EXACT = 0, FDW_NUMERICS_FAST = 1 };
 enum { FDW_DIALECT_RTM = 0, FDW_DIALECT_MOD = 1, FDW_DIALECT_RTM_STORED = 2 };
 /* 2 (FDW_DIALECT_RTM_STORED): the same sibling's stored-wavefield RTM (src/rtm_main.cpp): fd_step arithmetic as dialect 1, one-cell
  * source, taper_apply2 (top strip only, taper.c:68-83) with the taper table of dialect 1; only fdw_rtm_stored_shot uses it. */
@@ -283,6 +292,11 @@ int fdw_rand_stream(fdw_ctx *ctx, unsigned long long draw_offset, long long n, i
  *                         devices) or sit on different GPUs (peer copies over xGMI).  Every rank must be destroyed.
  * fdw_comm_init_stub      rank `rank` of a world whose other ranks do not exist: exchanges move nothing.  TIMING EXPERIMENTS ONLY (what
  *                         one rank of an N-way decomposition costs without its links: scripts/probe_slabs_c.py); results are wrong.
+ * fdw_comm_init_shm       one rank per PROCESS without RCCL: halo blocks are staged through the POSIX shared-memory segment `name` ("/..."; rank
+ *                         0 creates it, it is unlinked as soon as all ranks hold it), box_bytes = the largest message of one exchange
+ *                         (fields x ghost rows x pitch x 4).  A TEST TRANSPORT (ranks may share one GPU, which RCCL refuses): the ranks'
+ *                         streams are tied together by nothing but the arrival of a block, as under RCCL.  Collective.
+ * fdw_comm_kind           FDW_COMM_RCCL / FDW_COMM_LOCAL / FDW_COMM_SHM, 0 for a stub or NULL
  * fdw_comm_allreduce      one double per rank, summed (op_max = 0) or the maximum (op_max = 1); blocks the host.
  * fdw_comm_selftest       one block sent to the OWN rank through the backend's send / receive path on a stream, and compared.
  *
@@ -303,7 +317,10 @@ int fdw_rand_stream(fdw_ctx *ctx, unsigned long long draw_offset, long long n, i
  *                         d_obs[.][nt-1-it], d_img [nxl][pitch] (owned rows meaningful).
  * fdw_slabs_shot          one shot of rtm_code's loop (R:496-520) on host arrays: every rank passes the GLOBAL v2[nxe][nze], srce[nt],
  *                         d_obs[nx][nt]; imloc[nx][nz] (global; accumulated into) and the optional P, PP [nxe][nze] receive this rank's
- *                         OWNED rows only.  Bit-identical to fdw_shot on the whole grid. */
+ *                         OWNED rows only.  Bit-identical to fdw_shot on the whole grid.
+ * fdw_slabs_set_stub      on = 1: this rank's halo exchanges move nothing from now on (the cycles keep their launches and stream hand-overs).
+ *                         MEASUREMENT ONLY: bench.py times the same window with and without the transfers to report the exposed
+ *                         communication fraction; results computed while it is on are wrong.  Every rank must switch together. */
 typedef struct fdw_comm fdw_comm;
 typedef struct fdw_slabs fdw_slabs;
 #define FDW_COMM_ID_BYTES 128
@@ -311,6 +328,9 @@ int fdw_comm_get_unique_id(char id[FDW_COMM_ID_BYTES]);
 int fdw_comm_init_rank(const char id[FDW_COMM_ID_BYTES], int rank, int world, int device, fdw_comm **out);
 int fdw_comm_init_local(int world, const int *devices, fdw_comm **out /* [world] */);
 int fdw_comm_init_stub(int rank, int world, int device, fdw_comm **out);
+int fdw_comm_init_shm(const char *name, int rank, int world, int device, size_t box_bytes, fdw_comm **out);
+enum { FDW_COMM_RCCL = 1, FDW_COMM_LOCAL = 2, FDW_COMM_SHM = 3 };
+int fdw_comm_kind(const fdw_comm *comm);
 void fdw_comm_destroy(fdw_comm *comm);
 int fdw_comm_rank(const fdw_comm *comm);
 int fdw_comm_world(const fdw_comm *comm);
@@ -331,6 +351,7 @@ int fdw_slabs_back_buffers(const fdw_slabs *s, int *nfb, int *nrb);
 int fdw_slabs_dev_back(fdw_slabs *s, float *const *f, float *const *r, const float *d_v2, const float *d_samples, int gz, float *d_img, int it0,
                        int nsteps, int role[4]);
 int fdw_slabs_shot(fdw_slabs *s, const float *v2, int sx, int sz, int gz, const float *srce, const float *d_obs, float *imloc, float *P, float *PP);
+int fdw_slabs_set_stub(fdw_slabs *s, int on);
 
 /* ---- tuning / introspection --------------------------------------------------------------------
  * fdw_set_tuning  xchunk = rows marched per wave (0 = auto), wz = waves of a block laid along z

@@ -22,6 +22,11 @@
  *
  * Build: gcc -O2 -ffp-contract=off (no FMA contraction: the reference is built with
  * --fmad=false, S Makefile:4) -- see oracle/Makefile.
+ *
+ * FAST numerics (orc_set_numerics(s, 1)): NOT the reference's arithmetic but the product's documented tolerance mode (include/fdwave.h
+ * fdw_params.numerics, csrc/fdw_device.h): the Laplacian as ONE chain of symmetric sums and fused multiply-adds, everything else as
+ * above.  Restated here (orc_lap_fast, explicit fmaf calls) so that the FAST kernels are checked bit for bit against a CPU statement of
+ * their own formula -- masks, extents, taper and injection included -- and not only to a tolerance against the exact arithmetic.
  */
 #include <math.h>
 #include <stdio.h>
@@ -229,6 +234,41 @@ void orc_kernel_lap(int order, int nx, int nz, int gx, int gz, const float *p, f
     }
 }
 
+/* FAST numerics (see the header): lap = c0 p + sum_k [cz_k (p(j-k) + p(j+k)) + cx_k (p(i-k) + p(i+k))], c0 = cz_0 + cx_0 in fp32, one chain:
+ * acc = c0 * p; per k = 1..h: acc = fma(z sum, cz_k, acc); acc = fma(x sum, cx_k, acc).  p points at the centre, sx = floats between rows. */
+static float orc_lap_fast(const float *p, size_t sx, int h, const float *coefsx, const float *coefsz)
+{
+    float c0 = coefsz[h] + coefsx[h];
+    float acc = c0 * p[0];
+    int k;
+    for (k = 1; k <= h; k++) {
+        float sz = p[-k] + p[k];
+        float sxs = p[-(long)(k * sx)] + p[k * sx];
+        acc = fmaf(sz, coefsz[h - k], acc);
+        acc = fmaf(sxs, coefsx[h - k], acc);
+    }
+    return acc;
+}
+
+/* kernel_lap's extents with the FAST Laplacian */
+void orc_kernel_lap_fast(int order, int nx, int nz, int gx, int gz, const float *p, float *lap,
+                         const float *coefsx, const float *coefsz)
+{
+    int half_order = order / 2, ti, tj;
+    int nti = gx < nx - 2 * half_order ? gx : nx - 2 * half_order;
+    int ntj = gz < nz - 2 * half_order ? gz : nz - 2 * half_order;
+#ifdef _OPENMP
+#pragma omp parallel for private(tj) schedule(static)
+#endif
+    for (ti = 0; ti < nti; ti++) {
+        int i = half_order + ti;
+        for (tj = 0; tj < ntj; tj++) {
+            int j = half_order + tj;
+            lap[(size_t)i * nz + j] = orc_lap_fast(p + (size_t)i * nz + j, (size_t)nz, half_order, coefsx, coefsz);
+        }
+    }
+}
+
 /* R:80-92: the literal 2. makes the sum double; only (v2*dt2)*lap is a float product. */
 void orc_kernel_time(int nx, int nz, int gx, int gz, const float *p, float *pp, const float *v2,
                      const float *lap, float dt2)
@@ -304,7 +344,15 @@ typedef struct {
     float coefs_x[65], coefs_z[65];
     float *taper_x, *taper_z;
     float *d_laplace; /* shared scratch like R:32; calloc'ed (device memory reads as zero) */
+    int numerics;     /* 0: the reference's arithmetic; 1: FAST (orc_lap_fast) */
 } orc_state;
+
+void orc_set_numerics(orc_state *s, int numerics) { s->numerics = numerics; }
+static void orc_lap_pass(const orc_state *s, const float *p, float *lap)
+{
+    if (s->numerics) orc_kernel_lap_fast(s->order, s->nxe, s->nze, s->xlim, s->zlim, p, lap, s->coefs_x, s->coefs_z);
+    else orc_kernel_lap(s->order, s->nxe, s->nze, s->xlim, s->zlim, p, lap, s->coefs_x, s->coefs_z);
+}
 
 orc_state *orc_init(int order, int nxe, int nze, int nxb, int nzb, int nt, float fac, float dx,
                     float dz, float dt, int compat)
@@ -336,7 +384,7 @@ static void orc_forward_step(orc_state *s, float **d_p, float **d_pp, const floa
     *d_pp = *d_p;
     *d_p = d_swap;
     orc_kernel_tapper(s->nxe, s->nze, s->nxb, s->nzb, s->xlim, s->ztap, *d_p, *d_pp, s->taper_x, s->taper_z);
-    orc_kernel_lap(s->order, s->nxe, s->nze, s->xlim, s->zlim, *d_p, s->d_laplace, s->coefs_x, s->coefs_z);
+    orc_lap_pass(s, *d_p, s->d_laplace);
     orc_kernel_time(s->nxe, s->nze, s->xlim, s->zlim, *d_p, *d_pp, v2, s->d_laplace, s->dt2);
     orc_kernel_src(s->nze, *d_pp, sx, sz, srce_it);
 }
@@ -373,12 +421,12 @@ void orc_fd_back(orc_state *s, const float *v2, const float *snap0, const float 
         if (it == 0 || it == 1) {
             memcpy(d_pp, it == 0 ? snap1 : snap0, n * sizeof(float)); /* R:304-314 */
         } else {
-            orc_kernel_lap(s->order, s->nxe, s->nze, s->xlim, s->zlim, d_p, s->d_laplace, s->coefs_x, s->coefs_z);
+            orc_lap_pass(s, d_p, s->d_laplace);
             orc_kernel_time(s->nxe, s->nze, s->xlim, s->zlim, d_p, d_pp, v2, s->d_laplace, s->dt2);
         }
         d_swap = d_pp; d_pp = d_p; d_p = d_swap; /* R:321-323 */
         orc_kernel_tapper(s->nxe, s->nze, s->nxb, s->nzb, s->xlim, s->ztap, d_pr, d_ppr, s->taper_x, s->taper_z);
-        orc_kernel_lap(s->order, s->nxe, s->nze, s->xlim, s->zlim, d_pr, s->d_laplace, s->coefs_x, s->coefs_z);
+        orc_lap_pass(s, d_pr, s->d_laplace);
         orc_kernel_time(s->nxe, s->nze, s->xlim, s->zlim, d_pr, d_ppr, v2, s->d_laplace, s->dt2);
         orc_kernel_sism(s->nxe, s->nze, s->nxb, s->nt, it, gz_, s->xlim, d_obs, d_ppr);
         orc_kernel_img(s->nxe, s->nze, s->nxb, s->nzb, s->xlim, s->zlim, imloc, d_p, d_ppr);
@@ -403,6 +451,16 @@ void orc_stencil(int order, int nxe, int nze, float dx, float dz, const float *i
  * [r0-h, r1+h) are damped in place first (they are exactly the rows this step reads).  The reference
  * has no decomposition; this is the per-slab restatement used by the CPU (gloo) tests of the halo
  * exchange logic -- with x_off=0, nxl=nxe, r0=t0=0, r1=t1=nxe it is orc_forward_step. */
+/* the same launch with the FAST Laplacian (fdw_dev_laplacian on a numerics = 1 context) */
+void orc_stencil_fast(int order, int nxe, int nze, float dx, float dz, const float *in, float *out)
+{
+    float cx[65], cz[65];
+    int gx = ((nxe - 1) / 32 + 1) * 32, gz = ((nze - 1) / 32 + 1) * 32;
+    orc_scaled_coefs(order, dx, dz, 1, cx, cz);
+    memset(out, 0, (size_t)nxe * nze * sizeof(float));
+    orc_kernel_lap_fast(order, nxe, nze, gx, gz, in, out, cx, cz);
+}
+
 void orc_slab_step(const orc_state *s, int x_off, int nxl, float *p, float *pp, const float *v2, int r0, int r1,
                    int t0, int t1, int sx_global, int sz, float srce_it)
 {
@@ -429,6 +487,10 @@ void orc_slab_step(const orc_state *s, int x_off, int nxl, float *p, float *pp, 
         if (g < h || g >= nxe - h || g >= h + s->xlim || l < h || l >= nxl - h) continue;
         for (j = h; j < nze - h && j < h + s->zlim; j++) {
             float acmx = 0, acmz = 0;
+            if (s->numerics) {
+                lap[(size_t)l * nze + j] = orc_lap_fast(p + (size_t)l * nze + j, (size_t)nze, h, s->coefs_x, s->coefs_z);
+                continue;
+            }
             for (io = 0; io <= s->order; io++) {
                 acmz += p[(size_t)l * nze + j + io - h] * s->coefs_z[io];
                 acmx += p[(size_t)(l + io - h) * nze + j] * s->coefs_x[io];
@@ -484,6 +546,10 @@ void orc_slab_back_iter(const orc_state *s, int x_off, int nxl, int step_source,
             if (g < h || g >= nxe - h || g >= h + s->xlim || l < h || l >= nxl - h) continue;
             for (j = h; j < nze - h && j < h + s->zlim; j++) {
                 float acmx = 0, acmz = 0;
+                if (s->numerics) {
+                    lap[(size_t)l * nze + j] = orc_lap_fast(p + (size_t)l * nze + j, (size_t)nze, h, s->coefs_x, s->coefs_z);
+                    continue;
+                }
                 for (io = 0; io <= s->order; io++) {
                     acmz += p[(size_t)l * nze + j + io - h] * s->coefs_z[io];
                     acmx += p[(size_t)(l + io - h) * nze + j] * s->coefs_x[io];

@@ -64,6 +64,8 @@ def _declare(L):
     L.orc_init.restype = C.c_void_p
     L.orc_init.argtypes = [C.c_int] * 6 + [C.c_float] * 4 + [C.c_int]
     L.orc_free.argtypes = [C.c_void_p]
+    L.orc_set_numerics.argtypes = [C.c_void_p, C.c_int]
+    L.orc_stencil_fast.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f32p, f32p]
     L.orc_fd_forward.argtypes = [C.c_void_p, f32p, f32p, f32p, C.c_int, C.c_int, f32p, C.c_int]
     L.orc_fd_back.argtypes = [C.c_void_p, f32p, f32p, f32p, f32p, C.c_int, f32p, C.c_int]
     L.orc_slab_step.argtypes = [C.c_void_p, C.c_int, C.c_int, f32p, f32p, f32p] + [C.c_int] * 6 + [C.c_float]
@@ -138,22 +140,27 @@ def extents(nxe, nze, nzb, compat):
     return a.value, b.value, c.value
 
 
-def stencil(order, nxe, nze, dx, dz, field):
+def stencil(order, nxe, nze, dx, dz, field, numerics=0):
     out = np.zeros((nxe, nze), np.float32)
-    lib().orc_stencil(order, nxe, nze, dx, dz, np.ascontiguousarray(field, np.float32).reshape(nxe, nze), out)
+    fn = lib().orc_stencil_fast if numerics else lib().orc_stencil
+    fn(order, nxe, nze, dx, dz, np.ascontiguousarray(field, np.float32).reshape(nxe, nze), out)
     return out
 
 
 class Oracle:
     """State of one reference fd_init (R:200-224) on the CPU."""
 
-    def __init__(self, order, nxe, nze, nxb, nzb, nt, fac, dx, dz, dt, compat=True, omp=False):
+    def __init__(self, order, nxe, nze, nxb, nzb, nt, fac, dx, dz, dt, compat=True, omp=False, numerics=0):
+        """numerics 0: the reference's arithmetic (what every parity pin refers to); 1: the product's FAST tolerance mode restated
+        (fdw_oracle.c orc_lap_fast) -- the checker of the FAST kernels' own formula, not a statement about the reference."""
         self.shape = (nxe, nze)
         self.nx, self.nz, self.nt = nxe - 2 * nxb, nze - 2 * nzb, nt
         self._lib = lib(omp)
         self._h = self._lib.orc_init(order, nxe, nze, nxb, nzb, nt, fac, dx, dz, dt, int(compat))
         if not self._h:
             raise ValueError("orc_init rejected the parameters")
+        if numerics:
+            self._lib.orc_set_numerics(self._h, int(numerics))
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -24,7 +24,7 @@ class Params(C.Structure):
     """struct fdw_params (fdwave.h) == the arguments of the reference's fd_init (fd-code.cu:200)."""
     _fields_ = [("order", C.c_int), ("nxe", C.c_int), ("nze", C.c_int), ("nxb", C.c_int), ("nzb", C.c_int),
                 ("nt", C.c_int), ("dx", C.c_float), ("dz", C.c_float), ("dt", C.c_float), ("fac", C.c_float),
-                ("compat", C.c_int), ("coef_cxx", C.c_int), ("dialect", C.c_int)]
+                ("compat", C.c_int), ("coef_cxx", C.c_int), ("dialect", C.c_int), ("numerics", C.c_int)]
 
 
 class Slab(C.Structure):
@@ -77,6 +77,8 @@ SIGNATURES = [
     ("fdw_comm_init_rank", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     ("fdw_comm_init_local", C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]),
     ("fdw_comm_init_stub", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    ("fdw_comm_init_shm", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(vp)]),
+    ("fdw_comm_kind", C.c_int, [vp]),
     ("fdw_comm_destroy", None, [vp]),
     ("fdw_comm_rank", C.c_int, [vp]),
     ("fdw_comm_world", C.c_int, [vp]),
@@ -95,6 +97,7 @@ SIGNATURES = [
     ("fdw_slabs_back_buffers", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("fdw_slabs_dev_back", C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), vp, vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     ("fdw_slabs_shot", C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, vp, vp]),
+    ("fdw_slabs_set_stub", C.c_int, [vp, C.c_int]),
     ("fdw_set_tuning", C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("fdw_get_tables", C.c_int, [vp, vp, vp, vp, vp]),
     ("fdw_get_extents", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -101,10 +101,12 @@ class FDWave:
     """One fd_init (fd-code.cu:200-224 / fd-source-code.cu:241-262) worth of state on one MI355X."""
 
     def __init__(self, order, nxe, nze, nxb=0, nzb=0, nt=0, fac=1.0, dx=1.0, dz=1.0, dt=0.0, *, compat=True,
-                 coef_cxx=False, device=0, slab=None, dialect=0):
+                 coef_cxx=False, device=0, slab=None, dialect=0, numerics=0):
         """dialect 0: the CUDA programs (stencil_code / rtm_code); 1: the forward-modelling producer of the CPU-serial sibling
-        (mod_main: model_shot only); 2: its stored-wavefield RTM (rtm_main: rtm_stored_shot only)."""
-        self.params = Params(order, nxe, nze, nxb, nzb, nt, dx, dz, dt, fac, int(compat), int(coef_cxx), int(dialect))
+        (mod_main: model_shot only); 2: its stored-wavefield RTM (rtm_main: rtm_stored_shot only).
+        numerics 0: the reference's arithmetic operation for operation (bit-exact); 1: FAST -- symmetric taps summed first + fused
+        multiply-adds in the Laplacian (fdwave.h), within 1e-5 of the former, RTM dialect only."""
+        self.params = Params(order, nxe, nze, nxb, nzb, nt, dx, dz, dt, fac, int(compat), int(coef_cxx), int(dialect), int(numerics))
         self._h = C.c_void_p()
         if slab is None:
             check(lib().fdw_create(C.byref(self.params), device, C.byref(self._h)))

@@ -62,6 +62,7 @@ struct fdw_ctx {
     int slap_x0 = 0, slap_x1 = 0, slap_z0 = 0, slap_z1 = 0; // stencil program (full interior)
     int upd_x1 = 0, upd_z1 = 0, tz_x1 = 0, xt_lo = 0, xt_hi = 0;
     float dt2 = 0.f, dx2inv = 0.f, dz2inv = 0.f;
+    float c0 = 0.f;                // FAST numerics: cz[h] + cx[h]
     float cx[FDW_MAX_ORDER + 1]{}, cz[FDW_MAX_ORDER + 1]{};    // RTM weights (C libm variant unless coef_cxx); dialect MOD: unscaled
     float* d_rec = nullptr;     // dialect MOD: trace samples [nt][nx] of one shot
     size_t rec_cap = 0;
@@ -160,6 +161,9 @@ static int validate(const fdw_params* p, const fdw_slab* s)
     if (p->dialect < FDW_DIALECT_RTM || p->dialect > FDW_DIALECT_RTM_STORED) return fail(FDW_EINVAL, "dialect=%d is unknown", p->dialect);
     if (p->dialect != FDW_DIALECT_RTM && p->order > 2 * kMaxFastHalfOrder)
         return fail(FDW_EINVAL, "dialects 1 and 2 are built for orders 2..%d", 2 * kMaxFastHalfOrder);
+    if (p->numerics != FDW_NUMERICS_EXACT && p->numerics != FDW_NUMERICS_FAST) return fail(FDW_EINVAL, "numerics=%d is unknown", p->numerics);
+    if (p->numerics == FDW_NUMERICS_FAST && p->dialect != FDW_DIALECT_RTM)
+        return fail(FDW_EINVAL, "numerics = FAST is defined for the RTM dialect (dialect %d keeps the sibling's arithmetic)", p->dialect);
     if (s->nxl <= p->order || s->x_off < 0 || s->x_off + s->nxl > p->nxe)
         return fail(FDW_EINVAL, "slab [%d,%d) does not fit the grid (nxe=%d) or is thinner than the stencil",
                     s->x_off, s->x_off + s->nxl, p->nxe);
@@ -252,6 +256,7 @@ extern "C" int fdw_create_slab(const fdw_params* prm, const fdw_slab* slab, int 
         c->cz[io] = mod ? w[io] : dz2inv * w[io];      // fd.c:33-34 scales inside every term
         c->cx[io] = mod ? w[io] : dx2inv * w[io];
     }
+    c->c0 = c->cz[c->h] + c->cx[c->h];      // FAST numerics: the centre point's weight (one fp32 add, part of that mode's definition)
     c->taper_x.assign(std::max(prm->nxb, 1), 1.0f);
     c->taper_z.assign(std::max(prm->nzb, 1), 1.0f);
     if (mod) {
@@ -424,6 +429,8 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
         a.inj = d_inj + (l0 + c->slab.x_off - g0);
     }
     a.dt2 = c->dt2;
+    a.c0 = c->c0;
+    a.numerics = c->prm.numerics;
     for (int io = 0; io <= 2 * kMaxFastHalfOrder; io++) {
         a.cx[io] = io <= c->prm.order ? c->cx[io] : 0.0f;
         a.cz[io] = io <= c->prm.order ? c->cz[io] : 0.0f;
@@ -563,6 +570,8 @@ static int step2_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
         a.inj2 = ex.inj2 + (l0 + c->slab.x_off - g0);
     }
     a.dt2 = c->dt2;
+    a.c0 = c->c0;
+    a.numerics = c->prm.numerics;
     for (int io = 0; io <= 2 * kMaxFastHalfOrder; io++) { a.cx[io] = c->cx[io]; a.cz[io] = c->cz[io]; }
     const int ncells = c->pitch / 4;
     a.nstrip = (ncells + 59) / 60;
@@ -702,6 +711,8 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
         a.rec = d_rec; a.rec_z = rec_z; a.rec_x0 = c->prm.nxb - c->slab.x_off; a.rec_n = c->nx;
     }
     a.dt2 = c->dt2;
+    a.c0 = c->c0;
+    a.numerics = c->prm.numerics;
     for (int io = 0; io <= 2 * kMaxFastHalfOrder; io++) { a.cx[io] = c->cx[io]; a.cz[io] = c->cz[io]; }
     const int ncells = c->pitch / 4, own = 64 - 2 * kPipeSteps;
     a.nstrip = (ncells + own - 1) / own;

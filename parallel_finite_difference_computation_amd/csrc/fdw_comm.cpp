@@ -11,9 +11,21 @@
 //          communication stream, ordered after the sender's stream by an event and held against the sender's next write by a second
 //          event -- the same dependencies a send in flight has.  Ranks may share one device (tests and rehearsals on a one-GPU box: RCCL
 //          refuses two ranks on one device) or sit on different devices of the node (peer copies over xGMI, no RCCL involved).
+//   shm    one rank per PROCESS without RCCL: halo blocks are staged through a POSIX shared-memory segment (device -> segment on the
+//          sender's stream, segment -> device on the receiver's), sequence numbers in the segment say when a block has arrived and when
+//          it has been taken.  A TEST TRANSPORT: it lets the slab drivers of fdw_slabs.cpp run as real processes whose streams know
+//          nothing of each other beyond message arrival -- which is what RCCL gives -- with all ranks on ONE GPU (tests/test_slabs_gpu.py,
+//          bench.py --backend shm).  Slow by design (two PCIe crossings per block); never chosen automatically.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
+#include <atomic>
+
+#include <cerrno>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -34,7 +46,7 @@ namespace {
 typedef struct ncclComm* ncclComm_t;
 typedef struct { char internal[FDW_COMM_ID_BYTES]; } ncclUniqueId;
 typedef int ncclResult_t;                       // ncclSuccess == 0
-enum { kNcclFloat = 7, kNcclSum = 0 };          // ncclFloat32, ncclSum (rccl.h ncclDataType_t / ncclRedOp_t)
+enum { kNcclFloat = 7, kNcclDouble = 8, kNcclSum = 0, kNcclMax = 2 };   // ncclFloat32, ncclFloat64, ncclSum, ncclMax (rccl.h:448-467)
 
 struct Rccl {
     void* so = nullptr;
@@ -117,6 +129,58 @@ struct LocalGroup {
     long red_gen = 0;
     double red_result = 0.0;
 };
+
+// ---- the process transport: one segment per communicator ----
+constexpr unsigned kShmMagic = 0xFD3A5EEDu;
+constexpr int kShmMaxWorld = 64;
+struct ShmBox {                                 // [rank * 2 + dir]: what `rank` sends towards rank - 1 (dir 0) / rank + 1 (dir 1)
+    std::atomic<long> posted;                   // sequence number of the last block the owner's stream has finished writing
+    std::atomic<long> taken;                    // ... the neighbour's stream has finished reading
+    size_t count;
+    int nfields;
+    char pad[256 - 2 * sizeof(std::atomic<long>) - sizeof(size_t) - sizeof(int)];
+};
+struct ShmHeader {
+    std::atomic<unsigned> magic;                // written last by rank 0
+    int world;
+    size_t cap_bytes;                           // payload capacity of one box
+    std::atomic<int> attached, detached;
+    std::atomic<int> red_count;
+    std::atomic<long> red_gen;
+    double red[kShmMaxWorld];
+    double red_result;
+};
+static_assert(sizeof(ShmBox) == 256, "box header");
+struct ShmSeg {
+    char* base = nullptr;
+    size_t bytes = 0;
+    bool pinned = false;
+    std::vector<long> seq;                      // exchanges this rank has started
+    ShmHeader* hdr() const { return reinterpret_cast<ShmHeader*>(base); }
+    static size_t hdr_bytes() { return (sizeof(ShmHeader) + 4095) / 4096 * 4096; }
+    ShmBox* box(int rank, int dir) const { return reinterpret_cast<ShmBox*>(base + hdr_bytes() + (size_t)(rank * 2 + dir) * (sizeof(ShmBox) + hdr()->cap_bytes)); }
+    float* data(int rank, int dir) const { return reinterpret_cast<float*>(reinterpret_cast<char*>(box(rank, dir)) + sizeof(ShmBox)); }
+};
+struct ShmFlag {                                // argument of the host function that publishes a sequence number behind the copies on a stream
+    std::atomic<long>* flag;
+    long seq;
+};
+void shm_publish(void* p)
+{
+    ShmFlag* f = static_cast<ShmFlag*>(p);
+    f->flag->store(f->seq, std::memory_order_release);
+    delete f;
+}
+template <class Pred>
+bool shm_wait(Pred&& ok)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0; !ok(); spins++) {
+        if (spins > 200) usleep(50);
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > kRendezvousTimeout) return false;
+    }
+    return true;
+}
 }  // namespace
 
 struct fdw_comm {
@@ -124,12 +188,14 @@ struct fdw_comm {
     bool stub = false;                          // fdw_comm_init_stub: nothing travels (timing experiments)
     ncclComm_t nccl = nullptr;                  // RCCL backend
     std::shared_ptr<LocalGroup> grp;            // local backend
+    std::unique_ptr<ShmSeg> shm;                // process transport
 };
 
 extern "C" int fdw_comm_rank(const fdw_comm* c) { return c ? c->rank : 0; }
 extern "C" int fdw_comm_world(const fdw_comm* c) { return c ? c->world : 1; }
 extern "C" int fdw_comm_device(const fdw_comm* c) { return c ? c->device : 0; }
 extern "C" int fdw_comm_is_local(const fdw_comm* c) { return c && c->grp ? 1 : 0; }
+extern "C" int fdw_comm_kind(const fdw_comm* c) { return !c ? 0 : (c->nccl ? FDW_COMM_RCCL : (c->grp ? FDW_COMM_LOCAL : (c->shm ? FDW_COMM_SHM : 0))); }
 
 extern "C" int fdw_comm_get_unique_id(char id[FDW_COMM_ID_BYTES])
 {
@@ -174,26 +240,99 @@ extern "C" int fdw_comm_init_stub(int rank, int world, int device, fdw_comm** ou
     return FDW_OK;
 }
 
-extern "C" int fdw_comm_init_local(int world, const int* devices, fdw_comm** out)
+// Rank 0 creates the segment, the others attach (whoever comes first waits for the other); once every rank holds a mapping the name is
+// unlinked, so nothing is left in /dev/shm whatever happens to the processes afterwards.
+extern "C" int fdw_comm_init_shm(const char* name, int rank, int world, int device, size_t box_bytes, fdw_comm** out)
 {
-    if (!out || world < 1) return fdw_fail(FDW_EINVAL, "comm_init_local: world=%d", world);
+    if (!out) return fdw_fail(FDW_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!name || name[0] != '/' || world < 1 || world > kShmMaxWorld || rank < 0 || rank >= world || box_bytes == 0)
+        return fdw_fail(FDW_EINVAL, "comm_init_shm: name must start with '/', rank %d of %d (at most %d), box_bytes %zu", rank, world, kShmMaxWorld, box_bytes);
+    HIP_TRY(hipSetDevice(device));
+    const size_t cap = (box_bytes + 4095) / 4096 * 4096;
+    const size_t bytes = ShmSeg::hdr_bytes() + (size_t)world * 2 * (sizeof(ShmBox) + cap);
+    int fd = -1;
+    if (rank == 0) {
+        (void)shm_unlink(name);      // a stale segment of a run that died
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) return fdw_fail(FDW_ECOMM, "shm_open(%s, create) failed: %s", name, strerror(errno));
+        if (ftruncate(fd, (off_t)bytes) != 0) {
+            const int e = errno;
+            close(fd);
+            (void)shm_unlink(name);
+            return fdw_fail(FDW_ECOMM, "ftruncate(%s, %zu) failed: %s", name, bytes, strerror(e));
+        }
+    } else {
+        const bool ok = shm_wait([&] {
+            fd = shm_open(name, O_RDWR, 0600);
+            if (fd < 0) return false;
+            struct stat st;
+            if (fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) return true;
+            close(fd);
+            fd = -1;
+            return false;
+        });
+        if (!ok) return fdw_fail(FDW_ECOMM, "rank %d waited %lds for rank 0 to create %s", rank, (long)kRendezvousTimeout.count(), name);
+    }
+    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+        if (rank == 0) (void)shm_unlink(name);
+        return fdw_fail(FDW_ECOMM, "mmap(%s, %zu) failed: %s", name, bytes, strerror(errno));
+    }
+    fdw_comm* c = new (std::nothrow) fdw_comm();
+    if (!c) {
+        munmap(m, bytes);
+        return fdw_fail(FDW_ENOMEM, "out of host memory");
+    }
+    c->rank = rank; c->world = world; c->device = device;
+    c->shm.reset(new ShmSeg());
+    c->shm->base = static_cast<char*>(m);
+    c->shm->bytes = bytes;
+    c->shm->seq.assign(1, 0);
+    ShmHeader* h = c->shm->hdr();
+    if (rank == 0) {      // a fresh segment is zero-filled: counters and sequence numbers start at 0
+        h->world = world;
+        h->cap_bytes = cap;
+        h->magic.store(kShmMagic, std::memory_order_release);
+    } else if (!shm_wait([&] { return h->magic.load(std::memory_order_acquire) == kShmMagic; }) || h->world != world || h->cap_bytes != cap) {
+        munmap(m, bytes);
+        c->shm->base = nullptr;
+        delete c;
+        return fdw_fail(FDW_ECOMM, "rank %d: segment %s was not initialised by rank 0 for %d ranks x %zu bytes", rank, name, world, cap);
+    }
+    // pinned: the staging copies become asynchronous DMA transfers (not required for correctness)
+    c->shm->pinned = hipHostRegister(m, bytes, hipHostRegisterPortable) == hipSuccess;
+    if (!c->shm->pinned) (void)hipGetLastError();
+    h->attached.fetch_add(1);
+    const bool all = shm_wait([&] { return h->attached.load() >= world; });
+    if (rank == 0) (void)shm_unlink(name);
+    if (!all) {
+        fdw_comm_destroy(c);
+        return fdw_fail(FDW_ECOMM, "rank %d waited %lds for all %d ranks to attach to %s", rank, (long)kRendezvousTimeout.count(), world, name);
+    }
+    *out = c;
+    return FDW_OK;
+}
+
+static int init_local_impl(int world, const int* devices, fdw_comm** out)
+{
     auto g = std::make_shared<LocalGroup>();
     g->world = world;
     g->box.resize((size_t)world * 2);
     g->seq.assign(world, 0);
     g->red.assign(world, 0.0);
-    for (int r = 0; r < world; r++) out[r] = nullptr;
     for (int r = 0; r < world; r++) {
         fdw_comm* c = new (std::nothrow) fdw_comm();
         if (!c) return fdw_fail(FDW_ENOMEM, "out of host memory");
         c->rank = r; c->world = world; c->device = devices ? devices[r] : 0; c->grp = g;
+        out[r] = c;      // from here on the caller's cleanup finds it (and the events created so far)
         HIP_TRY(hipSetDevice(c->device));
         for (int d = 0; d < 2; d++) {
             Mailbox& b = g->box[(size_t)r * 2 + d];
             b.device = c->device;
             HIP_TRY(hipEventCreateWithFlags(&b.ready, hipEventDisableTiming));
         }
-        out[r] = c;
     }
     // `done` events live on the RECEIVER's device: box (r, dir) is consumed by rank r -/+ 1
     for (int r = 0; r < world; r++)
@@ -206,10 +345,34 @@ extern "C" int fdw_comm_init_local(int world, const int* devices, fdw_comm** out
     return FDW_OK;
 }
 
+extern "C" int fdw_comm_init_local(int world, const int* devices, fdw_comm** out)
+{
+    if (!out || world < 1) return fdw_fail(FDW_EINVAL, "comm_init_local: world=%d", world);
+    for (int r = 0; r < world; r++) out[r] = nullptr;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    const int rc = init_local_impl(world, devices, out);
+    if (rc != FDW_OK) {      // nothing half-built is handed back: the ranks created so far go, with their events
+        for (int r = 0; r < world; r++) {
+            if (out[r]) fdw_comm_destroy(out[r]);
+            out[r] = nullptr;
+        }
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);      // the calling thread keeps the device it had
+    return rc;
+}
+
 extern "C" void fdw_comm_destroy(fdw_comm* c)
 {
     if (!c) return;
     if (c->nccl && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->nccl);
+    if (c->shm && c->shm->base) {
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();           // host functions that publish into the segment have run
+        if (c->shm->pinned) (void)hipHostUnregister(c->shm->base);
+        munmap(c->shm->base, c->shm->bytes);
+        c->shm->base = nullptr;
+    }
     if (c->grp) {      // the events of this rank's mailboxes go with it (the group itself lives until its last rank is gone)
         for (int d = 0; d < 2; d++) {
             Mailbox& b = c->grp->box[(size_t)c->rank * 2 + d];
@@ -244,6 +407,39 @@ int fdw_comm_exchange(fdw_comm* c, int nfields, float* const* fields, size_t sen
             }
         }
         NCCL_TRY(r->GroupEnd());
+        return FDW_OK;
+    }
+    if (c->shm) {
+        ShmSeg& sg = *c->shm;
+        const size_t bytes = count * sizeof(float);
+        if ((size_t)nfields * bytes > sg.hdr()->cap_bytes)
+            return fdw_fail(FDW_ECOMM, "exchange: %d fields x %zu bytes exceed the segment's box capacity %zu (fdw_comm_init_shm box_bytes)", nfields, bytes, sg.hdr()->cap_bytes);
+        const long seq = ++sg.seq[0];
+        // 1. my blocks into my boxes, behind everything queued on `stream`; the sequence number is published by a host function behind the copies
+        for (int d = 0; d < 2; d++) {
+            if (!(d == 0 ? has_lo : has_hi)) continue;
+            ShmBox* b = sg.box(c->rank, d);
+            if (!shm_wait([&] { return b->taken.load(std::memory_order_acquire) >= seq - 1; }))
+                return fdw_fail(FDW_ECOMM, "exchange %ld: rank %d waited %lds for its previous halo rows to be taken", seq, c->rank, (long)kRendezvousTimeout.count());
+            b->count = count; b->nfields = nfields;
+            for (int f = 0; f < nfields; f++)
+                HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(sg.data(c->rank, d)) + (size_t)f * bytes, fields[f] + (d == 0 ? send_lo : send_hi), bytes, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipLaunchHostFunc(stream, shm_publish, new ShmFlag{&b->posted, seq}));
+        }
+        // 2. the neighbours' blocks: wait (host) for their arrival in the segment, then segment -> ghost rows on my stream
+        for (int d = 0; d < 2; d++) {
+            if (!(d == 0 ? has_lo : has_hi)) continue;
+            const int nb = d == 0 ? c->rank - 1 : c->rank + 1;
+            ShmBox* b = sg.box(nb, 1 - d);
+            if (!shm_wait([&] { return b->posted.load(std::memory_order_acquire) >= seq; }))
+                return fdw_fail(FDW_ECOMM, "exchange %ld: rank %d waited %lds for the halo rows of rank %d", seq, c->rank, (long)kRendezvousTimeout.count(), nb);
+            if (b->posted.load() != seq || b->nfields != nfields || b->count != count)
+                return fdw_fail(FDW_ECOMM, "exchange %ld: rank %d and rank %d disagree (their message %ld: %d fields x %zu, mine %d x %zu)", seq, c->rank, nb,
+                                b->posted.load(), b->nfields, b->count, nfields, count);
+            for (int f = 0; f < nfields; f++)
+                HIP_TRY(hipMemcpyAsync(fields[f] + (d == 0 ? recv_lo : recv_hi), reinterpret_cast<char*>(sg.data(nb, 1 - d)) + (size_t)f * bytes, bytes, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipLaunchHostFunc(stream, shm_publish, new ShmFlag{&b->taken, seq}));
+        }
         return FDW_OK;
     }
     LocalGroup& g = *c->grp;
@@ -304,23 +500,34 @@ extern "C" int fdw_comm_allreduce(fdw_comm* c, double* value, int op_max)
     if (!c || !value) return fdw_fail(FDW_EINVAL, "allreduce: NULL argument");
     if (c->world == 1 || c->stub) return FDW_OK;
     if (c->nccl) {
-        // RCCL has no host values: bounce one float pair through the device (sum; max via the sign-split trick is not needed here)
+        // RCCL reduces device memory: one double per rank through a device word, ncclSum / ncclMax on ncclFloat64 (any value survives)
         HIP_TRY(hipSetDevice(c->device));
-        float* d = nullptr;
-        HIP_TRY(hipMalloc((void**)&d, (size_t)c->world * sizeof(float)));
-        std::vector<float> h(c->world, 0.0f);
-        h[c->rank] = (float)*value;
-        hipError_t e = hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+        double* d = nullptr;
+        HIP_TRY(hipMalloc((void**)&d, sizeof(double)));
+        hipError_t e = hipMemcpy(d, value, sizeof(double), hipMemcpyHostToDevice);
         ncclResult_t rc = 0;
-        if (e == hipSuccess) rc = rccl()->AllReduce(d, d, (size_t)c->world, kNcclFloat, kNcclSum, c->nccl, nullptr);
-        if (e == hipSuccess && rc == 0) e = hipDeviceSynchronize();
-        if (e == hipSuccess && rc == 0) e = hipMemcpy(h.data(), d, h.size() * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) rc = rccl()->AllReduce(d, d, 1, kNcclDouble, op_max ? kNcclMax : kNcclSum, c->nccl, nullptr);
+        if (e == hipSuccess && rc == 0) e = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess && rc == 0) e = hipMemcpy(value, d, sizeof(double), hipMemcpyDeviceToHost);
         (void)hipFree(d);
         if (rc != 0) return fdw_fail(FDW_ECOMM, "ncclAllReduce failed: %s", rccl()->GetErrorString(rc));
         if (e != hipSuccess) return fdw_fail(FDW_EHIP, "allreduce: %s", hipGetErrorString(e));
-        double acc = op_max ? h[0] : 0.0;
-        for (float v : h) acc = op_max ? (v > acc ? v : acc) : acc + v;
-        *value = acc;
+        return FDW_OK;
+    }
+    if (c->shm) {
+        ShmHeader* h = c->shm->hdr();
+        const long gen = h->red_gen.load(std::memory_order_acquire);
+        h->red[c->rank] = *value;
+        if (h->red_count.fetch_add(1, std::memory_order_acq_rel) + 1 == c->world) {
+            double acc = op_max ? h->red[0] : 0.0;
+            for (int r = 0; r < c->world; r++) acc = op_max ? (h->red[r] > acc ? h->red[r] : acc) : acc + h->red[r];
+            h->red_result = acc;
+            h->red_count.store(0, std::memory_order_relaxed);
+            h->red_gen.store(gen + 1, std::memory_order_release);
+        } else if (!shm_wait([&] { return h->red_gen.load(std::memory_order_acquire) != gen; })) {
+            return fdw_fail(FDW_ECOMM, "allreduce: rank %d waited %lds for the other ranks", c->rank, (long)kRendezvousTimeout.count());
+        }
+        *value = h->red_result;
         return FDW_OK;
     }
     LocalGroup& g = *c->grp;

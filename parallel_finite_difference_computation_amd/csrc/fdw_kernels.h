@@ -48,6 +48,8 @@ struct StepArgs {
     int xchunk, wz, nzblk, nblk, nper;  // launch geometry (fast kernel)
     float dt2;
     float cx[2 * kMaxFastHalfOrder + 1], cz[2 * kMaxFastHalfOrder + 1];
+    float c0;              // FAST numerics: cz[H] + cx[H], the weight of the centre point (formed on the host in fp32)
+    int numerics;          // 0 EXACT (the reference's operations), 1 FAST (symmetric sums + fma; fdw_device.h): picks the instantiation
     // FDW_MODE_MOD only: cz holds the UNSCALED weights, the spacings come separately (fd.c:24-36 scales per term)
     float dx2inv, dz2inv;
     float gw[4][4];        // expf(-(i*i + j*j)): the 7x7 Gaussian point source of ptsrc.c:49-55
@@ -87,6 +89,8 @@ struct Step2Args {
     int xchunk, nstrip, nzblk, nblk, nper;
     float dt2;
     float cx[2 * kMaxFastHalfOrder + 1], cz[2 * kMaxFastHalfOrder + 1];
+    float c0;              // FAST numerics: cz[H] + cx[H]
+    int numerics;          // 0 EXACT, 1 FAST (see StepArgs)
     // pipeline kernel in FDW_MODE_MOD only (see StepArgs): unscaled weights in cz, spacings, Gaussian source weights, trace samples
     float dx2inv, dz2inv;
     float gw[4][4];

@@ -216,6 +216,14 @@ extern "C" int fdw_slabs_geometry(const fdw_slabs* s, int* x_off, int* nxl, int*
     return FDW_OK;
 }
 
+extern "C" int fdw_slabs_set_stub(fdw_slabs* s, int on)
+{
+    if (!s) return fdw_fail(FDW_EINVAL, "slabs is NULL");
+    s->stub = on != 0;
+    s->fresh = false;
+    return FDW_OK;
+}
+
 extern "C" void* fdw_slabs_stream(fdw_slabs* s) { return s ? (void*)s->compute : nullptr; }
 
 extern "C" int fdw_slabs_synchronize(fdw_slabs* s)

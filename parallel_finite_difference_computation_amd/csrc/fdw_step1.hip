@@ -1,8 +1,17 @@
 // fdw_step1.hip -- one time step per pass: the fused register-ring kernel (all modes and dialects), the generic-order kernel, the
 // small utility kernels and their launchers.  Design notes: fdw_device.h.
+//
+// This file is compiled three times (csrc/Makefile) so that its ~70 instantiations build side by side:
+//   FDW_TU 0 (fdw_step1.o)       the RTM dialect with the reference's exact arithmetic, the generic-order kernel, the utility kernels
+//   FDW_TU 1 (fdw_step1_dd.o)    the dialects of the CPU-serial sibling (MOD, DD_FWD, DD_RECV)
+//   FDW_TU 2 (fdw_step1_fast.o)  the RTM dialect with FAST numerics (fdw_device.h)
 #include "fdw_device.h"
 
 #pragma clang fp contract(off)
+
+#ifndef FDW_TU
+#define FDW_TU 0
+#endif
 
 namespace fdw {
 
@@ -39,7 +48,7 @@ struct ShotView {
     float* rec;
 };
 
-template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false, bool BACK = false>
+template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false, bool BACK = false, int NUM = 0>
 __device__ __forceinline__ void march(const StepArgs& a, const ShotView& sv, const int lane, const int zs, const int xa, const int xe)
 {
     // BACK: one whole backward iteration of fd_back (R:317-329) in a single pass: the source field is reconstructed in a second
@@ -75,6 +84,8 @@ __device__ __forceinline__ void march(const StepArgs& a, const ShotView& sv, con
     const float inj_src = ((INJ == 1 || INJ == 3) && inj_here) ? sload(sv.inj, 0) : 0.0f;
     const bool rec_here = DD && (a.rec != nullptr) && (a.rec_z >= zs) && (a.rec_z < zs + 256);
     const CoefPairs<H> cpk = coef_pairs<H>(a.cx, a.cz);
+    const v2f c0p = v2f{a.c0, a.c0};                          // FAST numerics: weight of the centre point
+    static_assert(NUM == 0 || !DD, "FAST numerics are defined for the RTM dialect");
 
     // per-lane column masks and damping factors
     bool mlap[4], mupd[4], znc[4], znh[4], ihit[4];
@@ -229,7 +240,7 @@ __device__ __forceinline__ void march(const StepArgs& a, const ShotView& sv, con
                 const ZPairs zp = zpairs(lft, c, rgt);
                 static_for<2>([&](auto PP) {
                     constexpr int P = decltype(PP)::value;
-                    v2f lap2 = laplacian_pair<H, P>(zp, [&](auto IO) { return f4_pair(ring[(U + decltype(IO)::value) % R], P); }, cpk);
+                    v2f lap2 = lap_pair<NUM, H, P>(zp, [&](auto IO) { return f4_pair(ring[(U + decltype(IO)::value) % R], P); }, cpk, c0p);
                     if (zedge || xedge) lap2 = v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
                     if constexpr (LAPONLY) {
                         res.v[2 * P] = lap2.x;
@@ -282,7 +293,7 @@ __device__ __forceinline__ void march(const StepArgs& a, const ShotView& sv, con
                 const ZPairs fzp = zpairs(flft, fc, frgt);
                 static_for<2>([&](auto PP) {
                     constexpr int P = decltype(PP)::value;
-                    v2f lap2 = laplacian_pair<H, P>(fzp, [&](auto IO) { return f4_pair(fring[(U + decltype(IO)::value) % R], P); }, cpk);
+                    v2f lap2 = lap_pair<NUM, H, P>(fzp, [&](auto IO) { return f4_pair(fring[(U + decltype(IO)::value) % R], P); }, cpk, c0p);
                     if (zedge || xedge) lap2 = v2f{(rowok && mlap[2 * P]) ? lap2.x : 0.0f, (rowok && mlap[2 * P + 1]) ? lap2.y : 0.0f};
                     const v2f prod2 = (f4_pair(qv2[Q], P) * a.dt2) * lap2;
 #pragma unroll
@@ -351,7 +362,7 @@ __device__ __forceinline__ void march(const StepArgs& a, const ShotView& sv, con
         static_for<R>([&](auto UU) { row_step(rb, UU, std::true_type{}); });
 }
 
-template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false, bool BACK = false>
+template <int H, bool TAPER, int INJ, bool IMG, bool LAPONLY, int PF, bool DD = false, bool BACK = false, int NUM = 0>
 __global__ __launch_bounds__(256) void fdw_step_kernel(const StepArgs a)
 {
     // a batch of independent shots of one geometry fills the chip where one small grid cannot: blockIdx.y picks the shot
@@ -378,9 +389,10 @@ __global__ __launch_bounds__(256) void fdw_step_kernel(const StepArgs a)
     const int xa = a.r0 + chunk * a.xchunk;
     const int xe = min(xa + a.xchunk, a.r1);
     if (xa >= xe) return;
-    march<H, TAPER, INJ, IMG, LAPONLY, PF, DD, BACK>(a, sv, lane, zs, xa, xe);
+    march<H, TAPER, INJ, IMG, LAPONLY, PF, DD, BACK, NUM>(a, sv, lane, zs, xa, xe);
 }
 
+#if FDW_TU == 0
 // ------------------------------------------------------------------------------------------------
 // generic-order kernel: any even order up to FDW_MAX_ORDER, one thread per point, every tap from
 // global memory (L1/L2 absorb the reuse).  Same arithmetic, same lazy-taper rules; used for orders
@@ -402,12 +414,19 @@ __global__ __launch_bounds__(256) void fdw_generic_kernel(const StepArgs a, int 
     const size_t k = (size_t)r * a.pitch + z;
     float lap = 0.0f;
     if (r >= a.lap_x0 && r < a.lap_x1 && z >= a.lap_z0 && z < a.lap_z1) {
-        float acmz = 0.0f, acmx = 0.0f;
-        for (int io = 0; io <= 2 * h; ++io) {
-            acmz = acmz + generic_p(a, r, z + io - h, taper) * a.gcz[io];
-            acmx = acmx + generic_p(a, r + io - h, z, taper) * a.gcx[io];
+        if (a.numerics) {      // FAST: one chain of symmetric sums and fused multiply-adds (fdw_device.h)
+            lap = a.c0 * generic_p(a, r, z, taper);
+            for (int k = 1; k <= h; ++k)
+                lap = laplacian_fast_tap(lap, generic_p(a, r, z - k, taper), generic_p(a, r, z + k, taper), generic_p(a, r - k, z, taper),
+                                         generic_p(a, r + k, z, taper), a.gcz[h - k], a.gcx[h - k]);
+        } else {
+            float acmz = 0.0f, acmx = 0.0f;
+            for (int io = 0; io <= 2 * h; ++io) {
+                acmz = acmz + generic_p(a, r, z + io - h, taper) * a.gcz[io];
+                acmx = acmx + generic_p(a, r + io - h, z, taper) * a.gcx[io];
+            }
+            lap = acmz + acmx;
         }
-        lap = acmz + acmx;
     }
     float out;
     if (laponly) {
@@ -497,9 +516,15 @@ __global__ void fdw_selftest_kernel(const float* src, float* out)
     f4_store_rsrc(out + 128, 64u * 16u, off, v);
 }
 
+#endif   // FDW_TU == 0
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+#if FDW_TU == 0
+hipError_t launch_step_dd(const StepArgs& a, int h, int mode, int pf, hipStream_t s);        // fdw_step1_dd.o
+hipError_t launch_step_fastnum(const StepArgs& a, int h, int mode, hipStream_t s);           // fdw_step1_fast.o
+
 template <int H, int PF>
 static hipError_t launch_fast_hp(const StepArgs& a, int mode, hipStream_t s)
 {
@@ -509,9 +534,6 @@ static hipError_t launch_fast_hp(const StepArgs& a, int mode, hipStream_t s)
     case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_step_kernel<H, false, 0, false, false, PF>), grid, block, 0, s, a); break;
     case FDW_MODE_RECV:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, PF>), grid, block, 0, s, a); break;
     case FDW_MODE_LAP:   hipLaunchKernelGGL((fdw_step_kernel<H, false, 0, false, true, PF>), grid, block, 0, s, a); break;
-    case FDW_MODE_MOD:   hipLaunchKernelGGL((fdw_step_kernel<H, true, 3, false, false, PF, true>), grid, block, 0, s, a); break;
-    case FDW_MODE_DD_FWD:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 1, false, false, PF, true>), grid, block, 0, s, a); break;
-    case FDW_MODE_DD_RECV: hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, PF, true>), grid, block, 0, s, a); break;
     case FDW_MODE_BACK:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, PF, false, true>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
@@ -521,6 +543,8 @@ static hipError_t launch_fast_hp(const StepArgs& a, int mode, hipStream_t s)
 hipError_t launch_step_fast(const StepArgs& a, int h, int mode, int pf, hipStream_t s)
 {
     if (a.nper <= 0) return hipSuccess;
+    if (mode == FDW_MODE_MOD || mode == FDW_MODE_DD_FWD || mode == FDW_MODE_DD_RECV) return a.numerics ? hipErrorInvalidValue : launch_step_dd(a, h, mode, pf, s);
+    if (a.numerics) return launch_step_fastnum(a, h, mode, s);
     if (h == 4) {
         switch (pf) {
         case 1: return launch_fast_hp<4, 1>(a, mode, s);
@@ -535,7 +559,64 @@ hipError_t launch_step_fast(const StepArgs& a, int h, int mode, int pf, hipStrea
     default: return hipErrorInvalidValue;
     }
 }
+#elif FDW_TU == 1
+template <int H, int PF>
+static hipError_t launch_dd_hp(const StepArgs& a, int mode, hipStream_t s)
+{
+    const dim3 grid(8 * a.nper, a.nbatch > 1 ? a.nbatch : 1), block(256);
+    switch (mode) {
+    case FDW_MODE_MOD:     hipLaunchKernelGGL((fdw_step_kernel<H, true, 3, false, false, PF, true>), grid, block, 0, s, a); break;
+    case FDW_MODE_DD_FWD:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 1, false, false, PF, true>), grid, block, 0, s, a); break;
+    case FDW_MODE_DD_RECV: hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, PF, true>), grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+hipError_t launch_step_dd(const StepArgs& a, int h, int mode, int pf, hipStream_t s)
+{
+    if (h == 4) {
+        switch (pf) {
+        case 1: return launch_dd_hp<4, 1>(a, mode, s);
+        case 3: return launch_dd_hp<4, 3>(a, mode, s);
+        default: return launch_dd_hp<4, 2>(a, mode, s);
+        }
+    }
+    switch (h) {
+    case 1: return launch_dd_hp<1, 2>(a, mode, s);
+    case 2: return launch_dd_hp<2, 2>(a, mode, s);
+    case 3: return launch_dd_hp<3, 2>(a, mode, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+#elif FDW_TU == 2
+// FAST numerics: the same kernels with NUM = 1 (prefetch distance 2; the tuning knob only exists for the exact order-8 kernels)
+template <int H>
+static hipError_t launch_fastnum_h(const StepArgs& a, int mode, hipStream_t s)
+{
+    const dim3 grid(8 * a.nper, a.nbatch > 1 ? a.nbatch : 1), block(256);
+    switch (mode) {
+    case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_step_kernel<H, true, 1, false, false, 2, false, false, 1>), grid, block, 0, s, a); break;
+    case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_step_kernel<H, false, 0, false, false, 2, false, false, 1>), grid, block, 0, s, a); break;
+    case FDW_MODE_RECV:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, 2, false, false, 1>), grid, block, 0, s, a); break;
+    case FDW_MODE_LAP:   hipLaunchKernelGGL((fdw_step_kernel<H, false, 0, false, true, 2, false, false, 1>), grid, block, 0, s, a); break;
+    case FDW_MODE_BACK:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, 2, false, true, 1>), grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+hipError_t launch_step_fastnum(const StepArgs& a, int h, int mode, hipStream_t s)
+{
+    switch (h) {
+    case 1: return launch_fastnum_h<1>(a, mode, s);
+    case 2: return launch_fastnum_h<2>(a, mode, s);
+    case 3: return launch_fastnum_h<3>(a, mode, s);
+    case 4: return launch_fastnum_h<4>(a, mode, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+#endif
 
+#if FDW_TU == 0
 hipError_t launch_step_generic(const StepArgs& a, int h, int mode, hipStream_t s)
 {
     if (a.r1 <= a.r0) return hipSuccess;
@@ -651,5 +732,6 @@ hipError_t launch_selftest(const float* src, float* out, hipStream_t s)
     hipLaunchKernelGGL(fdw_selftest_kernel, dim3(1), dim3(64), 0, s, src, out);
     return hipGetLastError();
 }
+#endif   // FDW_TU == 0
 
 }  // namespace fdw

@@ -21,7 +21,7 @@ namespace fdw {
 // descriptor's range check (per-row SRSRC, offset 0xFFFFFFF0), so the stores are unconditional too.
 // Arithmetic per point and per step is exactly the one-step kernel's (same helpers), hence bit-identical.
 // ------------------------------------------------------------------------------------------------
-template <int H, bool TAPER, int INJ, bool IMG, int PF>
+template <int H, bool TAPER, int INJ, bool IMG, int PF, int NUM = 0>
 __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const int cs, const int xa, const int xe, f4* stash)
 {
     constexpr int R = ((2 * H + PF + PF - 1) / PF) * PF;   // ring turns == unroll factor (10 for H=4, PF=2)
@@ -38,6 +38,7 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
     const bool wave_tap = TAPER && (cs * 4 < a.ztap);
     const bool xtap = wave_tap && ((xa - 2 * H < a.xt_lo) || (xe + 2 * H > a.xt_hi));
     const CoefPairs<H> cpk = coef_pairs<H>(a.cx, a.cz);
+    const v2f c0p = v2f{a.c0, a.c0};                          // FAST numerics: weight of the centre point
     const bool inj_cols = (a.inj_z >= cs * 4) && (a.inj_z < cs * 4 + 256);
     // INJ == 1: point source at (inj_x, inj_z), samples inj[0] -> u^{n+1}, inj[1] -> u^{n+2}          (kernel_src, R:119-122)
     // INJ == 2: receiver row z = inj_z, rows [inj_x, inj_x+inj_n): inj[row-inj_x] -> u^{n+1}, inj2[..] -> u^{n+2} (kernel_sism)
@@ -146,7 +147,7 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
                 const ZPairs zp = zpairs(lft, c1, rgt);
                 static_for<2>([&](auto PP) {
                     constexpr int P = decltype(PP)::value;
-                    const v2f lap2 = laplacian_pair<H, P>(zp, [&](auto IO) { return f4_pair(ring1[(U + decltype(IO)::value) % R], P); }, cpk);
+                    const v2f lap2 = lap_pair<NUM, H, P>(zp, [&](auto IO) { return f4_pair(ring1[(U + decltype(IO)::value) % R], P); }, cpk, c0p);
                     const v2f prod2 = (f4_pair(qv2[Q], P) * a.dt2) * v2f{(rowok1 && mlap[2 * P]) ? lap2.x : 0.0f, (rowok1 && mlap[2 * P + 1]) ? lap2.y : 0.0f};
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
@@ -188,7 +189,7 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
                     const ZPairs zp = zpairs(lft, c2, rgt);
                     static_for<2>([&](auto PP) {
                         constexpr int P = decltype(PP)::value;
-                        const v2f lap2 = laplacian_pair<H, P>(zp, [&](auto IO) { return f4_pair(ring2[(U - 2 * H + decltype(IO)::value + R) % R], P); }, cpk);
+                        const v2f lap2 = lap_pair<NUM, H, P>(zp, [&](auto IO) { return f4_pair(ring2[(U - 2 * H + decltype(IO)::value + R) % R], P); }, cpk, c0p);
                         const v2f prod2 = (f4_pair(v2r, P) * a.dt2) * v2f{(rowok2 && mlap[2 * P]) ? lap2.x : 0.0f, (rowok2 && mlap[2 * P + 1]) ? lap2.y : 0.0f};
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
@@ -240,7 +241,7 @@ __device__ __forceinline__ void march2(const Step2Args& a, const int lane, const
         static_for<R>([&](auto UU) { row_step(mb, UU); });
 }
 
-template <int H, bool TAPER, int INJ, bool IMG, int PF>
+template <int H, bool TAPER, int INJ, bool IMG, int PF, int NUM = 0>
 __global__ __launch_bounds__(256, IMG ? 3 : (TAPER ? 4 : 2)) void fdw_step2_kernel(const Step2Args a)
 {
     const int lane = threadIdx.x & 63;
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256, IMG ? 3 : (TAPER ? 4 : 2)) void fdw_step2_kern
     if (xa >= xe) return;
     // per-wave LDS slab: 8 rows x 64 lanes x 16 B for the v2 rows waiting between step 1 (row s) and step 2 (row s-H)
     __shared__ f4 v2_stash[4][8 * 64];
-    march2<H, TAPER, INJ, IMG, PF>(a, lane, strip * 60 - 2, xa, xe, v2_stash[w]);
+    march2<H, TAPER, INJ, IMG, PF, NUM>(a, lane, strip * 60 - 2, xa, xe, v2_stash[w]);
 }
 
 hipError_t launch_step2(const Step2Args& a, int h, int mode, hipStream_t s)
@@ -265,6 +266,15 @@ hipError_t launch_step2(const Step2Args& a, int h, int mode, hipStream_t s)
     if (a.nper <= 0) return hipSuccess;
     if (h != 4) return hipErrorInvalidValue;
     const dim3 grid(8 * a.nper), block(256);
+    if (a.numerics) {      // FAST numerics (fdw_device.h)
+        switch (mode) {
+        case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_step2_kernel<4, true, 1, false, 2, 1>), grid, block, 0, s, a); break;
+        case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_step2_kernel<4, false, 0, false, 2, 1>), grid, block, 0, s, a); break;
+        case FDW_MODE_RECV:  hipLaunchKernelGGL((fdw_step2_kernel<4, true, 2, true, 2, 1>), grid, block, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (mode) {
     case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_step2_kernel<4, true, 1, false, 2>), grid, block, 0, s, a); break;
     case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_step2_kernel<4, false, 0, false, 2>), grid, block, 0, s, a); break;

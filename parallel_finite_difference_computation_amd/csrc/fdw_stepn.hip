@@ -60,11 +60,13 @@ __device__ __forceinline__ int pipe_fifo_slot(int m)
 // LEAN: the body for workgroups that touch neither the frame of the grid (no Laplacian / update masks, no row clamps), nor the damped strip,
 // nor the source (instantiate with TAPER = false, INJ = 0): the kernel picks it per workgroup (pipe_lean)
 // WK: 0 = the wave finds out at run time whether it is wave 0 (full body); 1 / 2 = compiled for wave 0 / for the other waves (lean body)
-template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0, int ROWS = FDW_PIPE_ROWS, bool LEAN = false, int WK = 0>
+// NUM: 0 = the reference's exact arithmetic, 1 = FAST numerics (symmetric sums + fused multiply-adds, fdw_device.h)
+template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0, int ROWS = FDW_PIPE_ROWS, bool LEAN = false, int WK = 0, int NUM = 0>
 __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const int k, const int cs, const int xa, const int xe,
                                        f4 (*link)[2][2][ROWS][64], f4 (*fifo)[64], f4 (*imf)[64] = nullptr, f4 (*linkx)[2][2][ROWS][64] = nullptr)
 {
     static_assert(!LEAN || (!TAPER && INJ == 0), "the lean body has no damping, no injection (and records no trace)");
+    static_assert(NUM == 0 || !DD, "FAST numerics are defined for the RTM dialect");
     constexpr bool IMG = (BK == 2 || BK == 4);
     constexpr int D = (BK == 4) ? 1 : 0;                      // this role runs D march steps behind
     constexpr int DL = (BK >= 3) ? 1 : 0;                     // ... so both roles of the fused kernel loop one step longer
@@ -98,6 +100,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
     const bool xtap = wave_tap && ((xa - NS * H < a.xt_lo) || (xe + NS * H > a.xt_hi));
     const CoefPairs<H> cpk = DD ? coef_pairs<H>(a.cz, a.cz) : coef_pairs<H>(a.cx, a.cz);      // DD: the unscaled weights (the spacings enter per term)
     const v2f ddinv = v2f{a.dz2inv, a.dx2inv};
+    const v2f c0p = v2f{a.c0, a.c0};                                      // FAST numerics: weight of the centre point
     const int blob = (INJ == 3) ? 3 : 0;                                  // INJ 3: 7x7 Gaussian source of the CPU-serial sibling (ptsrc.c:49-55)
     const bool inj_here = (INJ == 2) ? ((a.inj_z >= cs * 4) && (a.inj_z < cs * 4 + 256) && (a.inj_x < xe + NS * H) && (a.inj_x + a.inj_n > xa - NS * H))
                                      : ((INJ != 0) && (a.inj_z + blob >= cs * 4) && (a.inj_z - blob < cs * 4 + 256) && (a.inj_x + blob >= xa - NS * H) && (a.inj_x - blob < xe + NS * H));
@@ -275,7 +278,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         } else {
             const ZPairs zp = zpairs(lft, c1, rgt);
             v2f lapq[2];
-            laplacian_quad<H>(zp, [&](auto IO) -> const f4& { return ring[(U + decltype(IO)::value) % R]; }, cpk, lapq[0], lapq[1]);
+            lap_quad<NUM, H>(zp, [&](auto IO) -> const f4& { return ring[(U + decltype(IO)::value) % R]; }, cpk, c0p, lapq[0], lapq[1]);
             static_for<2>([&](auto PP) {
                 constexpr int P = decltype(PP)::value;
                 v2f lap2 = lapq[P];
@@ -387,7 +390,7 @@ __device__ __forceinline__ bool pipe_lean(const Step2Args& a, int cs, int xa, in
     return ok;
 }
 
-template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0>
+template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0, int NUM = 0>
 __global__ __launch_bounds__(64 * NS, (FDW_PIPE_ROWS != 1 || BK == 2) ? 3 : (DD ? FDW_DD_WG : 5)) void fdw_stepn_kernel(const Step2Args a)
 {
     const int lane = threadIdx.x & 63;
@@ -406,21 +409,21 @@ __global__ __launch_bounds__(64 * NS, (FDW_PIPE_ROWS != 1 || BK == 2) ? 3 : (DD 
     if constexpr (BK == 2) {
         static_assert(FDW_PIPE_ROWS == 1, "the image FIFO assumes one row per barrier");
         __shared__ f4 imf[16][64];                         // image rows on their way from wave to wave (a row is 3 (H + 1) = 15 steps under way)
-        marchn<H, NS, TAPER, INJ, PF, DD, BK>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo, imf);
+        marchn<H, NS, TAPER, INJ, PF, DD, BK, FDW_PIPE_ROWS, false, 0, NUM>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo, imf);
     } else if constexpr (BK == 0 && (FDW_PIPE_OPT & 32)) {
         // nine workgroups in ten of a large grid touch neither the frame, nor the damped strip, nor the source: they take the lean body
         const int cs = zb * (64 - 2 * NS) - NS;
         if (pipe_lean<H, NS, TAPER, INJ, DD>(a, cs, xa, xe)) {
             if constexpr ((FDW_PIPE_OPT & 128) != 0 && !DD) {
-                if (k == 0) marchn<H, NS, false, 0, PF, DD, 0, FDW_PIPE_ROWS, true, 1>(a, lane, k, cs, xa, xe, link, fifo);
-                else marchn<H, NS, false, 0, PF, DD, 0, FDW_PIPE_ROWS, true, 2>(a, lane, k, cs, xa, xe, link, fifo);
+                if (k == 0) marchn<H, NS, false, 0, PF, DD, 0, FDW_PIPE_ROWS, true, 1, NUM>(a, lane, k, cs, xa, xe, link, fifo);
+                else marchn<H, NS, false, 0, PF, DD, 0, FDW_PIPE_ROWS, true, 2, NUM>(a, lane, k, cs, xa, xe, link, fifo);
             } else {
-                marchn<H, NS, false, 0, PF, DD, 0, FDW_PIPE_ROWS, true>(a, lane, k, cs, xa, xe, link, fifo);
+                marchn<H, NS, false, 0, PF, DD, 0, FDW_PIPE_ROWS, true, 0, NUM>(a, lane, k, cs, xa, xe, link, fifo);
             }
         }
-        else marchn<H, NS, TAPER, INJ, PF, DD, BK>(a, lane, k, cs, xa, xe, link, fifo);
+        else marchn<H, NS, TAPER, INJ, PF, DD, BK, FDW_PIPE_ROWS, false, 0, NUM>(a, lane, k, cs, xa, xe, link, fifo);
     } else {
-        marchn<H, NS, TAPER, INJ, PF, DD, BK>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo);
+        marchn<H, NS, TAPER, INJ, PF, DD, BK, FDW_PIPE_ROWS, false, 0, NUM>(a, lane, k, zb * (64 - 2 * NS) - NS, xa, xe, link, fifo);
     }
 }
 
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(64 * NS, (FDW_PIPE_ROWS != 1 || BK == 2) ? 3 : (DD 
 // the pipeline of the receiver field one march step behind (role 4).  The source-field levels never leave the chip: the receiver wave of
 // level k reads F_{it+k}(row) from the link buffer the source-field wave k wrote it to for its own successor.  6 fields in + 5 out per
 // four iterations = 44 B/point (the two-pass form moves 92).  Both roles run the same number of march steps and reach one barrier per step.
-template <int H, int NS, int PF>
+template <int H, int NS, int PF, int NUM = 0>
 __global__ __launch_bounds__(128 * NS, 2) void fdw_back4_kernel(const Step2Args a)
 {
     const int lane = threadIdx.x & 63;
@@ -452,25 +455,25 @@ __global__ __launch_bounds__(128 * NS, 2) void fdw_back4_kernel(const Step2Args 
     if (k8 < NS) {
         if (kLean && pipe_lean<H, NS, false, 0>(a, cs, xa, xe)) {
             if constexpr (kSplit) {
-                if (k8 == 0) marchn<H, NS, false, 0, PF, false, 3, 1, true, 1>(a, lane, k8, cs, xa, xe, linkF, fifo);
-                else marchn<H, NS, false, 0, PF, false, 3, 1, true, 2>(a, lane, k8, cs, xa, xe, linkF, fifo);
+                if (k8 == 0) marchn<H, NS, false, 0, PF, false, 3, 1, true, 1, NUM>(a, lane, k8, cs, xa, xe, linkF, fifo);
+                else marchn<H, NS, false, 0, PF, false, 3, 1, true, 2, NUM>(a, lane, k8, cs, xa, xe, linkF, fifo);
             } else {
-                marchn<H, NS, false, 0, PF, false, 3, 1, true>(a, lane, k8, cs, xa, xe, linkF, fifo);
+                marchn<H, NS, false, 0, PF, false, 3, 1, true, 0, NUM>(a, lane, k8, cs, xa, xe, linkF, fifo);
             }
         } else {
-            marchn<H, NS, false, 0, PF, false, 3>(a, lane, k8, cs, xa, xe, linkF, fifo);
+            marchn<H, NS, false, 0, PF, false, 3, 1, false, 0, NUM>(a, lane, k8, cs, xa, xe, linkF, fifo);
         }
     } else {
         // receiver role: lean where the tile holds neither the damped strip nor the receiver line
         if (kLean && pipe_lean<H, NS, true, 2>(a, cs, xa, xe)) {
             if constexpr (kSplitR) {
-                if (k8 == NS) marchn<H, NS, false, 0, PF, false, 4, 1, true, 1>(a, lane, 0, cs, xa, xe, linkR, fifo, imf, linkF);
-                else marchn<H, NS, false, 0, PF, false, 4, 1, true, 2>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
+                if (k8 == NS) marchn<H, NS, false, 0, PF, false, 4, 1, true, 1, NUM>(a, lane, 0, cs, xa, xe, linkR, fifo, imf, linkF);
+                else marchn<H, NS, false, 0, PF, false, 4, 1, true, 2, NUM>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
             } else {
-                marchn<H, NS, false, 0, PF, false, 4, 1, true>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
+                marchn<H, NS, false, 0, PF, false, 4, 1, true, 0, NUM>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
             }
         } else {
-            marchn<H, NS, true, 2, PF, false, 4>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
+            marchn<H, NS, true, 2, PF, false, 4, 1, false, 0, NUM>(a, lane, k8 - NS, cs, xa, xe, linkR, fifo, imf, linkF);
         }
     }
 }
@@ -480,6 +483,17 @@ hipError_t launch_stepn(const Step2Args& a, int h, int mode, hipStream_t s)
     if (a.nper <= 0) return hipSuccess;
     if (h != 4) return hipErrorInvalidValue;
     const dim3 grid(8 * a.nper), block(64 * kPipeSteps);
+    if (a.numerics) {      // FAST numerics (fdw_device.h): the same kernels with NUM = 1; RTM dialect only
+        switch (mode) {
+        case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 1, FDW_PIPE_PF, false, 0, 1>), grid, block, 0, s, a); break;
+        case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, false, 0, FDW_PIPE_PF, false, 0, 1>), grid, block, 0, s, a); break;
+        case FDW_MODE_PLAIN_ALL: hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, false, 0, FDW_PIPE_PF, false, 1, 1>), grid, block, 0, s, a); break;
+        case FDW_MODE_RECV:  hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 2, FDW_PIPE_PF, false, 2, 1>), grid, block, 0, s, a); break;
+        case FDW_MODE_BACK4: hipLaunchKernelGGL((fdw_back4_kernel<4, kPipeSteps, FDW_PIPE_PF, 1>), grid, dim3(128 * kPipeSteps), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (mode) {
     case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 1, FDW_PIPE_PF>), grid, block, 0, s, a); break;
     case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, false, 0, FDW_PIPE_PF>), grid, block, 0, s, a); break;

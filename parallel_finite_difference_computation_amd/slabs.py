@@ -47,6 +47,15 @@ class Comm:
         check(lib().fdw_comm_init_stub(rank, world, device, C.byref(h)))
         return cls(h)
 
+    @classmethod
+    def shm(cls, name, rank, world, device=0, box_bytes=64 << 20):
+        """Rank `rank` of `world` PROCESSES that stage their halo blocks through the POSIX shared-memory segment `name` ('/...'): the test
+        transport that lets the C slab drivers run as real processes on one GPU.  Collective; box_bytes = largest message of one exchange."""
+        h = C.c_void_p()
+        check(lib().fdw_comm_init_shm(name.encode(), rank, world, device, box_bytes, C.byref(h)))
+        return cls(h)
+
+    kind = property(lambda self: {1: "rccl", 2: "local", 3: "shm"}.get(lib().fdw_comm_kind(self._h), "stub"))
     rank = property(lambda self: lib().fdw_comm_rank(self._h))
     world = property(lambda self: lib().fdw_comm_world(self._h))
     device = property(lambda self: lib().fdw_comm_device(self._h))
@@ -79,8 +88,8 @@ class Comm:
 class Slabs:
     """This rank's share of an x-slab decomposition (fdw_slabs_create).  Collective: every rank of `comm` constructs one."""
 
-    def __init__(self, order, nxe, nze, nxb, nzb, nt, fac, dx, dz, dt, comm=None, compat=True, device=0, ksteps=0):
-        self.params = Params(order, nxe, nze, nxb, nzb, nt, dx, dz, dt, fac, int(compat), 0, 0)
+    def __init__(self, order, nxe, nze, nxb, nzb, nt, fac, dx, dz, dt, comm=None, compat=True, device=0, ksteps=0, numerics=0):
+        self.params = Params(order, nxe, nze, nxb, nzb, nt, dx, dz, dt, fac, int(compat), 0, 0, int(numerics))
         self._h = C.c_void_p()
         self.comm = comm
         check(lib().fdw_slabs_create(C.byref(self.params), comm._h if comm is not None else None, device, ksteps, C.byref(self._h)))
@@ -123,6 +132,10 @@ class Slabs:
 
     def synchronize(self):
         check(lib().fdw_slabs_synchronize(self._h))
+
+    def set_stub(self, on):
+        """Measurement only: halo exchanges move nothing while on (bench.py's exposed-communication figure)."""
+        check(lib().fdw_slabs_set_stub(self._h, int(bool(on))))
 
     def shot(self, v2, sx, sz, gz, srce, d_obs, imloc=None, want_fields=False):
         """One shot of rtm_code's loop on the decomposed grid (global host arrays in; this rank's OWNED rows of imloc / P / PP out)."""

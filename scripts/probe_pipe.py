@@ -26,7 +26,7 @@ if len(sys.argv) > 1:
     cases = [c for c in cases if str(c[0][0]) in sys.argv[1:]]
 for (nx, nz), chunks in cases:
     for xchunk in chunks:
-        ctx = F.FDWave(8, nx, nz, 64, 64, 100, 0.75, 10.0, 10.0, 0.001, compat=False)
+        ctx = F.FDWave(8, nx, nz, 64, 64, 100, 0.75, 10.0, 10.0, 0.001, compat=False, numerics=int(os.environ.get("PIPE_NUMERICS", "0")))
         ctx.set_tuning(xchunk=xchunk, two_step=int(os.environ.get("PIPE_MODE", "4")))
         bufs = [torch.randn((nx, ctx.pitch), device=dev) * 1e-3 for _ in range(4)]
         for b in bufs:

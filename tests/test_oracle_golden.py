@@ -31,6 +31,44 @@ def test_forward_loop_known_answer(new_mod):
     assert PP[:408, :288].any()
 
 
+def test_fast_numerics_restatement_against_the_reference_goldens(new_mod):
+    """The oracle's restatement of the product's FAST tolerance mode (orc_lap_fast: symmetric sums + fmaf, one chain per point) -- not
+    the reference's arithmetic, so what it owes the reference is the north star's tolerance: the Laplacian golden within 1e-6 and the
+    hardware forward-loop golden (input.bin, 1 700 steps) within 1e-5, max norm and L2; the untouched rows and columns stay zero."""
+    inp = golden_field("stencil_input_415x295.f32", (415, 295))
+    gold = golden_field("stencil_lap_415x295.f32", (415, 295))
+    lap = O.stencil(8, 415, 295, 10.0, 10.0, inp, numerics=1)
+    assert rel_max(lap, gold) < 1e-6 and (lap != gold).any()
+    assert not lap[:4].any() and not lap[-4:].any() and not lap[:, :4].any() and not lap[:, -4:].any()
+    d = new_mod
+    orc = O.Oracle(d["order"], d["nxe"], d["nze"], d["nxb"], d["nzb"], d["nt"], d["fac"], d["dx"], d["dz"], d["dt"], compat=True, numerics=1)
+    P, _ = orc.forward(d["v2"], d["sx"], d["sz"], O.ricker_wavelet(d["nt"], d["dt"], d["fpeak"]))
+    g = d["golden_P"]
+    assert rel_max(P, g) < 1e-5 and np.linalg.norm(P - g) / np.linalg.norm(g) < 1e-5
+    assert not P[408:].any() and not P[:, 288:].any()
+
+
+def test_fast_numerics_formula_spelled_out():
+    """orc_lap_fast against the formula of include/fdwave.h written out with exact rational arithmetic: acc = c0 p, then per tap k one
+    fused multiply-add of the z pair sum and one of the x pair sum (each fma rounded once from the exact value)."""
+    from fractions import Fraction as Fr
+    f32 = np.float32
+    order, nxe, nze = 8, 13, 12
+    p = np.random.default_rng(3).standard_normal((nxe, nze)).astype(f32)
+    cx, cz = O.scaled_coefs(order, 7.5, 12.5, cxx=True)
+    h = order // 2
+    rnd = lambda q: f32(float(q))                        # Fraction -> nearest double -> nearest float (no tie within reach of these values)
+    want = np.zeros_like(p)
+    for i in range(h, nxe - h):
+        for j in range(h, nze - h):
+            acc = f32(f32(cz[h] + cx[h]) * p[i, j])
+            for k in range(1, h + 1):
+                acc = rnd(Fr(float(f32(p[i, j - k] + p[i, j + k]))) * Fr(float(cz[h - k])) + Fr(float(acc)))
+                acc = rnd(Fr(float(f32(p[i - k, j] + p[i + k, j]))) * Fr(float(cx[h - k])) + Fr(float(acc)))
+            want[i, j] = acc
+    assert_bit_equal(O.stencil(order, nxe, nze, 7.5, 12.5, p, numerics=1), want, "orc_lap_fast vs the formula")
+
+
 def test_full_extent_mode_differs_from_compat(new_mod):
     # guards the compat switch: with full launch extents the late-time field is a different answer
     d = new_mod

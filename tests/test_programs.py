@@ -367,6 +367,40 @@ def test_multi_process_bench_rehearsal_on_one_gpu(ranks, opts, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("workload,backend", [("forward", "gloo"), ("forward", "shm"), ("rtm-slab", "shm")])
+def test_bench_starts_its_own_ranks(workload, backend, tmp_path):
+    """`python bench.py --gpus 2 ...` exactly as the driver calls it -- no launcher, no RANK / WORLD_SIZE in the environment: the parent starts
+    the two ranks itself (before anything touches HIP), rank 0's JSON line is the LAST line on stdout, n_gpus = 2, exit status 0, and the
+    decomposed result equals the single-domain one bitwise.  gloo: the Python harness; shm: the C slab driver (fdw_slabs_*) over the
+    process transport of fdw_comm.cpp -- the code RCCL drives on a multi-GPU node, here with the two ranks sharing this box's GPU."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", backend, "--size", "1024", "--steps", "24", "--warmup", "6",
+           "--check", "--no-cpu-baseline", "--workload", workload]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tmp_path, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = [ln for ln in r.stdout.splitlines() if ln.strip()][-1]
+    out = json.loads(last)
+    assert out["n_gpus"] == 2 and out["result_finite_nonzero"] and out["value"] > 0
+    assert out["launched_by"].startswith("bench.py itself")
+    assert "bitwise equal" in out["decomposition_check"]
+    if backend == "shm":
+        assert out["rccl_ranks"] is None and out["comm_ranks"] == 2 and "process transport" in out["halo_exchange"]
+        assert 0.0 <= out["exposed_comm_fraction"] <= 1.0
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_reports_a_failing_rank(tmp_path):
+    """A rank that dies must not leave the launcher waiting: non-zero exit, no JSON line."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "shm", "--size", "1024", "--steps", "8", "--warmup", "4",
+                        "--no-cpu-baseline", "--ksteps", "200"], capture_output=True, text=True, timeout=600, cwd=tmp_path, env=env)      # ghost rows wider than a band
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
 def test_bench_multi_gpu_code_path_on_one_rank(tmp_path):
     """bench.py's --backend nccl path (communicator over librccl, fdw_slabs_dev_forward: the code the 8-GPU run executes) forced onto one
     rank: the JSON line must come out and agree with the plain single-GPU path on the field it ends with (finite, non-zero)."""

@@ -67,6 +67,56 @@ def test_c_slab_driver_ranks_as_threads_on_one_gpu(world, ksteps, shape, compat,
         c.close()
 
 
+@pytest.mark.parametrize("world,ksteps,shape,compat,pipe", [(2, 4, (400, 500), True, False), (3, 3, (701, 523), True, False), (3, 8, (900, 2100), False, True),
+                                                            (2, 4, (333, 2500), True, True), (3, 0, (1400, 1100), False, None)],
+                         ids=["2procs-k4", "3procs-k3-ragged", "3procs-pipeline-k8", "2procs-pipeline-k4-ragged", "3procs-auto"])
+def test_c_slab_driver_as_real_processes(world, ksteps, shape, compat, pipe, tmp_path):
+    """fdw_slabs_shot as `world` PROCESSES sharing this GPU, halo blocks through the library's process transport (fdw_comm_init_shm): no
+    rank's streams know anything of another's beyond the arrival of a block -- what RCCL gives on a multi-GPU node, and what the
+    ranks-as-threads communicator (whose host-side rendezvous orders more than that) cannot show.  Image, P and PP gathered from the
+    processes' owned rows equal fdw_shot on the whole grid bit for bit: one-step and pipeline cycles, ragged compat extents, leftovers."""
+    import os
+    import subprocess
+    import sys
+    nxe, nze = shape
+    nt = 2 * max(ksteps, 4) + 5
+    d, srce, d_obs, im0 = _case(nxe, nze, 40, nt, compat)
+    want, P, PP = _single(d, srce, d_obs, im0)
+    case = tmp_path / "case.npz"
+    np.savez(case, v2=d["v2"], srce=srce, d_obs=d_obs, im0=im0, numerics=0, **{k: d[k] for k in ("order", "nxe", "nze", "nxb", "nzb", "nt", "fac", "dx", "dz", "dt", "compat", "sx", "sz", "gz")})
+    env = dict(os.environ)
+    env.pop("FDW_SLAB_PIPE", None)
+    if pipe is not None:
+        env["FDW_SLAB_PIPE"] = "1" if pipe else "0"
+    name = f"/fdw_test_{os.getpid()}_{world}_{ksteps}"
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "slab_rank_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(case), name, str(r), str(world), str(ksteps), str(tmp_path / f"out{r}.npz")], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(lg[-2000:] for lg in logs)
+    img, gP, gPP = np.array(im0), np.zeros_like(P), np.zeros_like(PP)
+    rows = 0
+    for r in range(world):
+        z = np.load(tmp_path / f"out{r}.npz")
+        o0, o1, a, b = z["own"]
+        img[a:b], gP[o0:o1], gPP[o0:o1] = z["img"], z["P"], z["PP"]
+        rows += o1 - o0
+        if pipe is not None:
+            assert (int(z["nbuf"]) == 4) == pipe
+    assert rows == nxe
+    assert_bit_equal(gPP, PP, "PP gathered from the processes")
+    assert_bit_equal(gP, P, "P gathered from the processes")
+    assert_bit_equal(img, want, "image gathered from the processes")
+    assert np.abs(want - im0).max() > 0
+
+
 def test_c_slab_driver_single_rank_equals_fdw_shot():
     d, srce, d_obs, im0 = _case(210, 300, 24, 21, True, dx=25.0, dz=8.0)
     want, P, PP = _single(d, srce, d_obs, im0)
