@@ -92,6 +92,11 @@ int fdw_version(void);
  *                  rows (or more) towards every neighbouring slab.
  * fdw_destroy      replaces the cudaFree block R:569-582 / S:264-275. */
 int fdw_create(const fdw_params *prm, int device, fdw_ctx **out);
+/* fdw_device_count   HIP devices visible to this process (0 when there is none or HIP cannot start).
+ * fdw_device_usable  0 if `device` exists, is a gfx950 and can be selected -- what a rank of a multi-GPU job checks ALONE before it enters
+ *                    a collective call (rtm_code slabs=N). */
+int fdw_device_count(void);
+int fdw_device_usable(int device);
 int fdw_create_slab(const fdw_params *prm, const fdw_slab *slab, int device, fdw_ctx **out);
 void fdw_destroy(fdw_ctx *ctx);
 
@@ -371,6 +376,9 @@ int fdw_get_extents(const fdw_ctx *ctx, int *xlim, int *zlim, int *ztap);
 int fdw_two_step_active(const fdw_ctx *ctx); /* 1 if the forward loops of this context use the two-step kernel */
 int fdw_steps_per_pass(const fdw_ctx *ctx);  /* time steps one launch of the forward loops advances: 4 (wave pipeline), 2 or 1 */
 int fdw_selftest(fdw_ctx *ctx);
+/* 1 if the host loops emit roctx ranges (forward loop, backward loop, halo exchange, shot): they do when a marker library
+ * (librocprofiler-sdk-roctx / libroctx64) is already in the process -- rocprofv3 --marker-trace -- or FDW_ROCTX=1 asks for it. */
+int fdw_trace_active(void);
 
 /* ---- host formulas of libsource.a restated (pure C, usable without a device) --------------------
  * fdw_calc_coefs        calc_coefs + makeo2, F:113-192 / S:137-216 (cxx selects the float variant)

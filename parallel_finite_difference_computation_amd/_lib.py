@@ -36,6 +36,8 @@ SIGNATURES = [
     ("fdw_last_error", C.c_char_p, []),
     ("fdw_version", C.c_int, []),
     ("fdw_create", C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(vp)]),
+    ("fdw_device_count", C.c_int, []),
+    ("fdw_device_usable", C.c_int, [C.c_int]),
     ("fdw_create_slab", C.c_int, [C.POINTER(Params), C.POINTER(Slab), C.c_int, C.POINTER(vp)]),
     ("fdw_destroy", None, [vp]),
     ("fdw_laplacian", C.c_int, [vp, f32p, f32p]),
@@ -104,6 +106,7 @@ SIGNATURES = [
     ("fdw_two_step_active", C.c_int, [vp]),
     ("fdw_steps_per_pass", C.c_int, [vp]),
     ("fdw_selftest", C.c_int, [vp]),
+    ("fdw_trace_active", C.c_int, []),
     ("fdw_calc_coefs", C.c_int, [C.c_int, C.c_int, f32p]),
     ("fdw_ricker_wavelet", None, [C.c_int, C.c_float, C.c_float, f32p]),
     ("fdw_taper_tables", None, [C.c_int, C.c_int, C.c_float, vp, vp]),

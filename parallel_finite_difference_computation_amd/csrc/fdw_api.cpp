@@ -305,6 +305,28 @@ extern "C" int fdw_create_slab(const fdw_params* prm, const fdw_slab* slab, int 
     return FDW_OK;
 }
 
+extern "C" int fdw_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+extern "C" int fdw_device_usable(int device)
+{
+    const int n = fdw_device_count();
+    if (device < 0 || device >= n) return fail(FDW_ENODEVICE, "device %d does not exist (%d visible)", device, n);
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(FDW_ENODEVICE, "hipGetDeviceProperties(%d): %s", device, hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(FDW_ENODEVICE, "device %d is %s; libfdwave is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail(FDW_ENODEVICE, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    return FDW_OK;
+}
+
 extern "C" int fdw_create(const fdw_params* prm, int device, fdw_ctx** out)
 {
     if (!prm) return fail(FDW_EINVAL, "params is NULL");
@@ -380,6 +402,11 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
     if (mode_dialect != c->prm.dialect)
         return fail(FDW_ESTATE, "step: mode %d does not belong to this context's dialect %d", mode, c->prm.dialect);
     if (r0 < 0 || r1 > c->nxl || r0 > r1) return fail(FDW_EINVAL, "step: rows [%d,%d) outside the slab (%d rows)", r0, r1, c->nxl);
+    // d_out (the new field stored somewhere else than over pp) is honoured by the register-ring kernel's DD_FWD instantiation only -- the one
+    // caller, fdw_rtm_stored_shot, whose store slots are zero-filled so that cells the kernel never stores equal what an in-place update
+    // would have left there.  Anything else would silently update in place: refuse.
+    if (d_out && (mode != FDW_MODE_DD_FWD || c->h > kMaxFastHalfOrder || c->use_generic || d_out == d_p || d_out == d_pp))
+        return fail(FDW_EINVAL, "step: a separate output array is supported by the DD_FWD register-ring kernel only, and must not alias the inputs");
 
     StepArgs a{};
     a.p = d_p; a.pp = d_pp; a.v2 = d_v2; a.psrc = d_psrc; a.img = d_img; a.fpp = d_fpp;
@@ -965,6 +992,7 @@ static int upload_source(fdw_ctx* c, const float* srce, int n)
 // through the two-step kernel where it pays); *ip / *ipp index (d_p, d_pp) before the loop and after it.
 static int forward_loop(fdw_ctx* c, int* ip, int* ipp, int sx, int sz, int nsteps)
 {
+    FDW_RANGE("fdw: forward loop (fd_forward)");
     int rc = fdw_dev_steps2(c, c->fld, c->d_v2, c->d_srce, sx, sz, 0, nsteps, 0, ip, ipp, c->stream);
     if (rc) return rc;
     if (nsteps > 0) return fdw_dev_taper_finalize(c, c->fld[*ip], c->stream);   // the T() d_p still owes (R:285 downloads the damped d_p)
@@ -1034,6 +1062,7 @@ static int image_to_host(fdw_ctx* c, float* imloc)
 // otherwise.  src[0..3] / rcv[0..3]: rotating buffers; on entry src[0] = snap0, src[1] = snap1, the receivers are zero.
 static int back_loop(fdw_ctx* c, float* const src[4], float* const rcv[4], int gz, int nsteps)
 {
+    FDW_RANGE("fdw: backward loop + imaging (fd_back)");
     const int nt = c->prm.nt;
     const size_t nxs = (size_t)c->nx;
     auto samples = [&](int it) { return c->d_dobs + (size_t)(nt - 1 - it) * nxs; };
@@ -1158,6 +1187,7 @@ extern "C" int fdw_back(fdw_ctx* c, const float* v2, const float* snap0, const f
 static int shot_impl(fdw_ctx* c, const float* v2, int sx, int sz, int gz, const float* srce, const float* d_obs, float* imloc, float* P, float* PP)
 {
     if (!c || !srce || !d_obs || !imloc) return fail(FDW_EINVAL, "NULL argument");
+    FDW_RANGE("fdw: shot (uploads, forward, backward, image download)");
     if (!is_full_grid(c)) return fail(FDW_EINVAL, "fdw_shot needs a full-grid context");
     if (c->nx <= 0 || c->nz <= 0) return fail(FDW_EINVAL, "no interior to image");
     HIP_TRY(hipSetDevice(c->device));

@@ -31,7 +31,8 @@ fdw_deck *fdw_deck_read(const char *path)
     fdw_deck *d = (fdw_deck *)calloc(1, sizeof *d);
     char *line = NULL;
     size_t len = 0;
-    while (getline(&line, &len, fp) != -1) {
+    int oom = d == NULL;
+    while (!oom && getline(&line, &len, fp) != -1) {
         char *hash = strchr(line, '#');
         if (hash) *hash = '\0';
         char *eq = strchr(line, '=');
@@ -39,17 +40,36 @@ fdw_deck *fdw_deck_read(const char *path)
         *eq = '\0';
         char *k = trim(line), *v = trim(eq + 1);
         if (!*k) continue;
-        if (d->n == d->cap) {
-            d->cap = d->cap ? 2 * d->cap : 32;
-            d->key = (char **)realloc(d->key, d->cap * sizeof(char *));
-            d->val = (char **)realloc(d->val, d->cap * sizeof(char *));
+        if (d->n == d->cap) {      /* grow both tables or neither: a failed realloc leaves the old block (and the deck) intact */
+            const int cap = d->cap ? 2 * d->cap : 32;
+            char **nk = (char **)realloc(d->key, (size_t)cap * sizeof(char *));
+            if (nk) d->key = nk;
+            char **nv = nk ? (char **)realloc(d->val, (size_t)cap * sizeof(char *)) : NULL;
+            if (nv) d->val = nv;
+            if (!nk || !nv) {
+                oom = 1;
+                break;
+            }
+            d->cap = cap;
         }
-        d->key[d->n] = strdup(k);
-        d->val[d->n] = strdup(v);
+        char *kc = strdup(k), *vc = strdup(v);
+        if (!kc || !vc) {
+            free(kc);
+            free(vc);
+            oom = 1;
+            break;
+        }
+        d->key[d->n] = kc;
+        d->val[d->n] = vc;
         d->n++;
     }
     free(line);
     fclose(fp);
+    if (oom) {
+        fprintf(stderr, "out of memory while reading input deck '%s'\n", path);
+        fdw_deck_free(d);
+        return NULL;
+    }
     return d;
 }
 

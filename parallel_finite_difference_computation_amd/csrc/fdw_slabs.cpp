@@ -85,6 +85,7 @@ struct fdw_slabs {
     int exchange(int n, float* const* f)
     {
         if (world == 1) return FDW_OK;
+        FDW_RANGE("fdw: halo exchange (enqueue)");
         FDW_TRY(wait(commS, send_after ? send_after : compute));
         send_after = nullptr;
         if (!stub)
@@ -245,6 +246,7 @@ extern "C" int fdw_slabs_dev_forward(fdw_slabs* s, float* const* buf, const floa
                                      int first_pp_twice, int* ip, int* ipp)
 {
     if (!s || !buf || !d_v2 || !ip || !ipp) return fdw_fail(FDW_EINVAL, "slabs forward: NULL argument");
+    FDW_RANGE("fdw: slab forward loop (enqueue)");
     const int nb = s->nbuf;
     if (*ip < 0 || *ip >= nb || *ipp < 0 || *ipp >= nb || *ip == *ipp) return fdw_fail(FDW_EINVAL, "slabs forward: bad buffer indices %d, %d", *ip, *ipp);
     HIP_TRY(hipSetDevice(s->device));
@@ -338,6 +340,7 @@ extern "C" int fdw_slabs_dev_back(fdw_slabs* s, float* const* f, float* const* r
                                   int it0, int nsteps, int role[4])
 {
     if (!s || !f || !r || !d_v2 || !d_samples || !d_img || !role) return fdw_fail(FDW_EINVAL, "slabs back: NULL argument");
+    FDW_RANGE("fdw: slab backward loop + imaging (enqueue)");
     for (int i = 0; i < 4; i++)      // without the pipeline only the four named buffers are touched (they may sit anywhere among four)
         if (role[i] < 0 || role[i] >= 4) return fdw_fail(FDW_EINVAL, "slabs back: role[%d] = %d outside the rotating buffers", i, role[i]);
     if (role[0] == role[1] || role[2] == role[3]) return fdw_fail(FDW_EINVAL, "slabs back: a pair names one buffer twice");

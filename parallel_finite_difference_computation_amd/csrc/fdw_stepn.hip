@@ -31,6 +31,9 @@ namespace fdw {
 #ifndef FDW_DD_WG
 #define FDW_DD_WG 4
 #endif
+#ifndef FDW_PIPE_WG
+#define FDW_PIPE_WG 5      // workgroups per CU the forward kernels are held to by their launch bounds (5 x 4 waves: 96 VGPRs)
+#endif
 #ifndef FDW_PIPE_OPT
 #define FDW_PIPE_OPT 993   // 1: waves skip the march steps outside their useful window; 4: the frame masks only in workgroups that touch the frame;
                            // 32: workgroups away from the frame, the damped strip and the sources run the lean body (pipe_lean);
@@ -391,7 +394,7 @@ __device__ __forceinline__ bool pipe_lean(const Step2Args& a, int cs, int xa, in
 }
 
 template <int H, int NS, bool TAPER, int INJ, int PF, bool DD = false, int BK = 0, int NUM = 0>
-__global__ __launch_bounds__(64 * NS, (FDW_PIPE_ROWS != 1 || BK == 2) ? 3 : (DD ? FDW_DD_WG : 5)) void fdw_stepn_kernel(const Step2Args a)
+__global__ __launch_bounds__(64 * NS, (FDW_PIPE_ROWS != 1 || BK == 2) ? 3 : (DD ? FDW_DD_WG : FDW_PIPE_WG)) void fdw_stepn_kernel(const Step2Args a)
 {
     const int lane = threadIdx.x & 63;
     const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -119,18 +119,30 @@ typedef struct {
     fdw_slabs *slabs;
 } slab_rank;
 
+/* Opening a rank is collective from ncclCommInitRank on (RCCL has no timeout: a rank that never arrives leaves the others waiting for
+ * ever, holding their GPUs), so it goes in two phases with a barrier in between: first everything a rank can check ALONE -- its device
+ * exists, is a gfx950 and can be selected --, then, only if no rank failed, the collective calls.  Every rank (the main thread included)
+ * calls this exactly once and reaches both barriers. */
 static int slab_rank_open(slab_rank *r)
 {
     slab_job *j = r->job;
-    int rc = FDW_OK;
-    if (j->local) r->comm = j->local_comms[r->rank];
-    else rc = fdw_comm_init_rank(j->uid, r->rank, j->world, r->rank, &r->comm);      /* rank r drives GPU r */
-    if (rc == FDW_OK) rc = fdw_slabs_create(j->prm, r->comm, 0, 0, &r->slabs);
+    int rc = j->local ? FDW_OK : fdw_device_usable(r->rank);                         /* rank r drives GPU r */
     if (rc != FDW_OK) {
         fprintf(stderr, "rank %d: %s\n", r->rank, fdw_last_error());
         j->failed = 1;
     }
-    return rc;
+    pthread_barrier_wait(j->bar);       /* O1: every rank has checked its device */
+    if (!j->failed) {
+        if (j->local) r->comm = j->local_comms[r->rank];
+        else rc = fdw_comm_init_rank(j->uid, r->rank, j->world, r->rank, &r->comm);
+        if (rc == FDW_OK) rc = fdw_slabs_create(j->prm, r->comm, 0, 0, &r->slabs);
+        if (rc != FDW_OK) {
+            fprintf(stderr, "rank %d: %s\n", r->rank, fdw_last_error());
+            j->failed = 1;
+        }
+    }
+    pthread_barrier_wait(j->bar);       /* O2: every rank is open (or the job has failed) */
+    return j->failed ? FDW_ECOMM : FDW_OK;
 }
 static void slab_rank_shot(slab_rank *r, int is)
 {
@@ -236,6 +248,12 @@ int main(int argc, char **argv)
     prm.dx = dx; prm.dz = dz; prm.dt = dt; prm.fac = fac;
     prm.compat = 1;   /* the reference's launch extents, R:185-195 */
     prm.coef_cxx = 0; /* libsource.a is C, F:160-192 */
+    {                 /* our extension, absent = the reference's arithmetic: numerics=1 (or FDW_NUMERICS=1) selects FAST numerics (fdwave.h) */
+        int numerics = fdw_deck_int(deck, "numerics");
+        if (getenv("FDW_NUMERICS")) numerics = atoi(getenv("FDW_NUMERICS"));
+        prm.numerics = numerics == 1 ? FDW_NUMERICS_FAST : FDW_NUMERICS_EXACT;
+        if (prm.numerics) printf("## numerics = FAST (symmetric sums + fused multiply-adds in the Laplacian; within 1e-5 of the reference's arithmetic)\n");
+    }
 
     float *img = (float *)calloc(ni, sizeof(float)), *img_lap = (float *)calloc(ni, sizeof(float));
     FILE *fsns = open_out(tmpdir, "dir.snaps"), *fsns2 = open_out(tmpdir, "dir.snaps_rec"), *fsnr = open_out(tmpdir, "dir.snapr");
@@ -261,7 +279,14 @@ int main(int argc, char **argv)
         /* ---- every shot on `slabs` GPUs: bands of rows, halo exchange inside the library ---- */
         slab_job sj;
         memset(&sj, 0, sizeof sj);
-        sj.prm = &prm; sj.world = slabs; sj.local = getenv("FDW_SLABS_LOCAL") != NULL; sj.ns = ns; sj.nx = nx; sj.nt = nt; sj.sz = sz; sj.gz = gz;
+        sj.local = getenv("FDW_SLABS_LOCAL") != NULL;
+        const int ndev = fdw_device_count();
+        if (ndev < 1 || (!sj.local && slabs > ndev)) {      /* before any thread or communicator exists: RCCL would wait for the missing ranks for ever */
+            fprintf(stderr, "slabs=%d needs %d GPUs, one rank each; %d visible%s\n", slabs, slabs, ndev < 0 ? 0 : ndev,
+                    ndev >= 1 ? " (FDW_SLABS_LOCAL=1 runs the ranks as threads sharing GPU 0: rehearsals only)" : "");
+            return EXIT_FAILURE;
+        }
+        sj.prm = &prm; sj.world = slabs; sj.ns = ns; sj.nx = nx; sj.nt = nt; sj.sz = sz; sj.gz = gz;
         sj.sx = sx; sj.srce = srce; sj.d_obs = d_obs;
         float *v2 = (float *)malloc(ne * sizeof(float)), *imloc = (float *)calloc(ni, sizeof(float));
         fdw_comm *lc[64];

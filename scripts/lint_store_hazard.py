@@ -1,9 +1,19 @@
 #!/usr/bin/env python3
-"""Static check of the BUILT libfdwave.so for the gfx950 store hazard of csrc/fdw_device.h (f4_store_arr): a buffer_store_dwordx3/x4 whose
-soffset is an SGPR must not be followed, within two wait states, by an instruction that writes one of its data VGPRs (hipcc pads that pair
-only for stores without a register soffset; the hardware was seen to store the NEW value).
+"""Static check of the BUILT libfdwave.so for the gfx950 store-data hazard (csrc/fdw_device.h, f4_store_arr): a 96- or 128-bit vector
+memory store must not be followed, within two wait states, by a VALU instruction that writes one of its data VGPRs -- the store still
+reads them (round 2 saw the NEW value stored on some launches).  hipcc's hazard recogniser pads buffer stores WITHOUT a register soffset
+and flat / global stores (two wait states on gfx940+), but not buffer stores WITH one; the kernels pad those themselves (s_nop 1).  This
+lint does not trust either: it checks EVERY x3/x4 store in the library -- buffer_store (any soffset), global_store, flat_store,
+scratch_store -- whoever padded it.
 
     python3 scripts/lint_store_hazard.py [path/to/libfdwave.so]        exit code 1 and one line per finding if any
+
+What is followed: straight-line successors AND branch targets -- an s_branch / s_cbranch_* inside the window counts as one wait state and
+both the target and (for a conditional branch) the fall-through are examined, so a store at the end of a loop body followed by a VALU
+write at the loop head is found.  s_setpc / s_swappc / s_endpgm end a path (nothing to follow statically).
+What counts as a writer: VALU instructions (v_*), the case the hardware hazard is about.  Memory instructions that name a data VGPR as
+destination (buffer_load, global_load, ds_read, ds_bpermute ...) deliver it hundreds of cycles after issue, far outside the window; they
+are listed as notes, never as findings.
 
 Disassembles every gfx950 code object embedded in the library (llvm-objcopy, clang-offload-bundler, llvm-objdump of the ROCm install), so
 it checks what actually runs, inline asm included.  No GPU needed."""
@@ -55,51 +65,92 @@ def disassemble(lib):
             yield i, subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout
 
 
+STORE = re.compile(r"(buffer|global|flat|scratch)_store_dwordx[34]$")
+WINDOW = 2          # wait states the data registers stay busy (gfx940+: LLVM's VALUWaitStates for this hazard; measured in round 2)
+
+
+def parse(text):
+    """[(func, addr, mnemonic, operands, line)] per code object, None between symbols; addr from objdump's '// 0000000012A0:' comment."""
+    insts, func = [], "?"
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            func = m.group(1)
+            insts.append(None)
+            continue
+        m = re.match(r"^\s+([a-z_0-9]+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", line)
+        if m:
+            ops = [o.strip() for o in m.group(2).split(",")] if m.group(2) else []
+            insts.append((func, int(m.group(3), 16), m.group(1), ops, line.strip()))
+    return insts
+
+
+def branch_target(ins):
+    """Byte address an s_branch / s_cbranch_* jumps to: PC of the next instruction + 4 * simm16."""
+    try:
+        imm = int(ins[3][0].split()[0], 0)
+    except (IndexError, ValueError):
+        return None
+    if imm >= 0x8000:
+        imm -= 0x10000
+    return ins[1] + 4 + 4 * imm
+
+
 def check(lib):
-    findings, nstores, nkernels = [], 0, 0
+    findings, notes, nstores, nkernels, nbranches = [], [], 0, 0, 0
     for unit, text in disassemble(lib):
-        func = "?"
-        insts = []
-        for line in text.splitlines():
-            m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
-            if m:
-                func = m.group(1)
-                nkernels += 1
-                insts.append(None)                    # no fall-through bookkeeping across symbols
-                continue
-            m = re.match(r"^\s+([a-z_0-9]+)\s*(.*?)\s*//", line)
-            if m:
-                ops = [o.strip() for o in m.group(2).split(",")] if m.group(2) else []
-                insts.append((func, m.group(1), ops, line.strip()))
+        insts = parse(text)
+        nkernels += sum(1 for x in insts if x is None)
+        by_addr = {ins[1]: k for k, ins in enumerate(insts) if ins is not None}
         for i, ins in enumerate(insts):
-            if ins is None or not re.match(r"buffer_store_dwordx[34]$", ins[1]):
-                continue
-            ops = ins[2]
-            # buffer_store_dwordx4 vdata, voffset|off, srsrc, soffset [offen ...]
-            soff = ops[3].split()[0] if len(ops) > 3 else "0"
-            if not re.fullmatch(r"s\d+|m0|vcc_lo|vcc_hi|ttmp\d+", soff):
+            if ins is None or not STORE.match(ins[2]):
                 continue
             nstores += 1
-            data = vregs(ops[0])
-            states = 0
-            for nxt in insts[i + 1:i + 4]:
-                if nxt is None or states >= 2:
-                    break
-                if nxt[1] == "s_nop":
-                    states += int(nxt[2][0], 0) + 1 if nxt[2] else 1
-                    continue
-                hit = written_vgprs(nxt[1], nxt[2]) & data
-                if hit and nxt[1].startswith("v_"):
-                    findings.append(f"code object {unit}, {ins[0]}: '{ins[3].split('//')[0].strip()}' then '{nxt[3].split('//')[0].strip()}' after {states} wait state(s)")
-                    break
-                states += 1
-    return findings, nstores, nkernels
+            data = vregs(ins[3][0]) if ins[2].startswith("buffer") else (vregs(ins[3][1]) if len(ins[3]) > 1 else set())
+            if not data:
+                continue
+            here = ins[4].split("//")[0].strip()
+            seen = set()
+            todo = [(i + 1, 0)]                                   # (index of the next instruction on this path, wait states already passed)
+            while todo:
+                k, states = todo.pop()
+                while states < WINDOW and k < len(insts) and insts[k] is not None and (k, states) not in seen:
+                    seen.add((k, states))
+                    nxt = insts[k]
+                    mn = nxt[2]
+                    if mn == "s_nop":
+                        states += int(nxt[3][0], 0) + 1 if nxt[3] else 1
+                        k += 1
+                        continue
+                    if mn in ("s_endpgm", "s_setpc_b64", "s_swappc_b64"):
+                        break
+                    if mn == "s_branch" or mn.startswith("s_cbranch"):
+                        nbranches += 1
+                        t = branch_target(nxt)
+                        if t in by_addr:
+                            todo.append((by_addr[t], states + 1))
+                        if mn == "s_branch":
+                            break
+                        states += 1
+                        k += 1
+                        continue
+                    hit = written_vgprs(mn, nxt[3]) & data
+                    if hit:
+                        msg = f"code object {unit}, {ins[0]}: '{here}' then '{nxt[4].split('//')[0].strip()}' after {states} wait state(s)"
+                        (findings if mn.startswith("v_") else notes).append(msg)
+                        break
+                    states += 1
+                    k += 1
+    return findings, nstores, nkernels, notes, nbranches
 
 
 if __name__ == "__main__":
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "parallel_finite_difference_computation_amd", "libfdwave.so")
-    f, ns, nk = check(lib)
-    print(f"{os.path.basename(lib)}: {nk} symbols, {ns} x3/x4 buffer stores with a register soffset, {len(f)} within two wait states of a VALU write of their data")
+    f, ns, nk, notes, nb = check(lib)
+    print(f"{os.path.basename(lib)}: {nk} symbols, {ns} 96/128-bit vector stores (buffer / global / flat / scratch), {nb} branches followed inside a window, "
+          f"{len(f)} within {WINDOW} wait states of a VALU write of their data, {len(notes)} followed by a memory instruction that names a data register (harmless, see docstring)")
     for line in f:
         print("  " + line)
+    for line in notes[:20]:
+        print("  note: " + line)
     sys.exit(1 if f else 0)

@@ -25,6 +25,33 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert L.fdw_version() == 2      # fdw_params grew `numerics` (FDW_VERSION 2)
 
 
+def test_cpu_side_c_is_clean_under_the_sanitizers(tmp_path):
+    """`make -C oracle asan`: the product's host C (csrc/fdw_host.c, csrc/fdw_config.c) and both oracle files built with
+    -fsanitize=address,undefined -fno-sanitize-recover=all and driven by tests/sanitize_host.c through the deck reader (shipped decks and
+    hostile ones: 70 000-character lines, 5 000 keys, no trailing newline), every host formula for every order and border shape, and the
+    oracle's loops on ragged grids in both numerics modes.  Any finding aborts; the reference has no sanitizer build at all."""
+    import subprocess
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([os.path.join(ROOT, "oracle", "sanitize_host"), os.path.join(ROOT, "tests", "golden", "decks"), str(tmp_path)], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0 and "sanitize_host: clean" in r.stdout, (r.stdout + r.stderr)[-4000:]
+
+
+def test_roctx_ranges_are_off_by_default_and_on_when_asked():
+    """The host loops carry roctx ranges (csrc/fdw_trace.cpp, marker library through dlopen): nothing is loaded by default, FDW_ROCTX=1 (or a
+    profiler's marker library already in the process) switches them on.  No GPU needed: the ranges are host-side."""
+    import subprocess
+    import sys
+    code = "import parallel_finite_difference_computation_amd as F; print(F.lib().fdw_trace_active())"
+    env = {k: v for k, v in os.environ.items() if k != "FDW_ROCTX"}
+    off = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert off.returncode == 0 and off.stdout.strip() == "0", off.stderr
+    if os.path.exists("/opt/rocm/lib/librocprofiler-sdk-roctx.so.1") or os.path.exists("/opt/rocm/lib/libroctx64.so.4"):
+        on = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=dict(env, FDW_ROCTX="1"))
+        assert on.returncode == 0 and on.stdout.strip() == "1", on.stderr
+
+
 def test_create_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

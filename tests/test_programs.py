@@ -173,6 +173,34 @@ def test_rtm_code_program_vs_oracle_pipeline(tmp_path, with_vel_ext):
     assert np.allclose(last, img, rtol=1e-5, atol=1e-5 * np.abs(img).max())
 
 
+def test_rtm_code_refuses_more_slabs_than_gpus(tmp_path):
+    """slabs=N over RCCL needs N GPUs, one rank each: with fewer visible (none in the authoring container, one on a GPU box) the program must
+    say so and exit at once -- before it creates a communicator or a thread, because a rank that never arrives would leave the others
+    waiting inside ncclCommInitRank for ever."""
+    _small_rtm_case(tmp_path, False, ns=1)
+    (tmp_path / "input.dat").write_text((tmp_path / "input.dat").read_text() + "slabs=64\n")
+    env = {k: v for k, v in os.environ.items() if k != "FDW_SLABS_LOCAL"}
+    r = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=tmp_path, capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "needs 64 GPUs" in r.stderr, r.stderr + r.stdout
+
+
+@pytest.mark.gpu
+def test_rtm_code_fast_numerics_deck_key(tmp_path):
+    """Deck key numerics=1 (our extension; absent = the reference's arithmetic): the image stays within 1e-5 of the exact program's, and is
+    not the same bits."""
+    a, b = tmp_path / "exact", tmp_path / "fast"
+    a.mkdir()
+    nx, nz, *_ = _small_rtm_case(a, True, ns=2, ds=14)
+    shutil.copytree(a, b)
+    (b / "input.dat").write_text((b / "input.dat").read_text() + "numerics=1\n")
+    for d in (a, b):
+        r = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=d, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr + r.stdout
+    assert "numerics = FAST" in r.stdout
+    ia, ib = (np.fromfile(d / "output" / "dir.image", np.float32) for d in (a, b))
+    assert np.abs(ia - ib).max() / np.abs(ia).max() < 1e-5 and (ia != ib).any()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("with_vel_ext", [False, True])
 def test_rtm_code_slab_mode_matches_the_serial_program(tmp_path, with_vel_ext):
@@ -612,9 +640,10 @@ def test_committed_bench_lines_keep_the_contract():
 
 
 def test_built_library_has_no_store_followed_by_a_write_of_its_data():
-    """scripts/lint_store_hazard.py on the built libfdwave.so: no buffer_store_dwordx3/x4 with a register soffset is followed within two wait
-    states by a VALU write of its data registers (the gfx950 hazard of csrc/fdw_device.h, f4_store_arr; the check reads the disassembly
-    of the embedded gfx950 code objects, so it needs the ROCm tools but no GPU)."""
+    """scripts/lint_store_hazard.py on the built libfdwave.so: no 96 / 128-bit vector store (buffer with or without a register soffset, global,
+    flat, scratch) is followed within two wait states -- along straight-line code or across a branch -- by a VALU write of its data
+    registers (the gfx950 hazard of csrc/fdw_device.h, f4_store_arr; the check reads the disassembly of the embedded gfx950 code objects, so
+    it needs the ROCm tools but no GPU)."""
     import importlib.util
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
     lib = os.path.join(root, "parallel_finite_difference_computation_amd", "libfdwave.so")
@@ -623,6 +652,26 @@ def test_built_library_has_no_store_followed_by_a_write_of_its_data():
     spec = importlib.util.spec_from_file_location("lint_store_hazard", os.path.join(root, "scripts", "lint_store_hazard.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    findings, nstores, nsymbols = mod.check(lib)
-    assert nsymbols > 20 and nstores >= 100, "the disassembly was not read (no kernels / no pipeline stores found)"
+    findings, nstores, nsymbols, notes, nbranches = mod.check(lib)
+    assert nsymbols > 20 and nstores >= 1000 and nbranches > 0, "the disassembly was not read (no kernels / no stores / no branch inside a window found)"
     assert not findings, "\n".join(findings)
+    # the walker itself: a store at the end of a loop body whose data register is rewritten at the loop head, and the padded form
+    loop = """
+0000000000001000 <k>:
+	v_mov_b32_e32 v40, v1                                      // 000000001000: 7E500301
+	s_nop 0                                                    // 000000001004: BF800000
+	buffer_store_dwordx4 v[40:43], v48, s[8:11], s18 offen     // 000000001008: E07C1000 12022830
+	s_cbranch_scc1 65532                                       // 000000001010: BF85FFFC
+	s_endpgm                                                   // 000000001014: BF810000
+"""
+    insts = mod.parse(loop)
+    assert mod.branch_target(insts[4]) == 0x1004 and insts[3][2] == "buffer_store_dwordx4"
+    orig = mod.disassemble
+    try:
+        mod.disassemble = lambda _lib: iter([(0, loop.replace("65532", "65531"))])           # back to the v_mov: one wait state (the branch) in between
+        found = mod.check("x")[0]
+        assert len(found) == 1 and "v_mov_b32" in found[0]
+        mod.disassemble = lambda _lib: iter([(0, loop)])                                       # back to the s_nop behind it: two wait states, clean
+        assert mod.check("x")[0] == []
+    finally:
+        mod.disassemble = orig
