@@ -101,7 +101,7 @@ import torch  # noqa: E402
 sys.path.insert(0, ROOT)
 
 import parallel_finite_difference_computation_amd as F  # noqa: E402
-from parallel_finite_difference_computation_amd.decomp import HipSlabStepper, SlabForward, SlabGeometry  # noqa: E402
+from parallel_finite_difference_computation_amd.decomp import SlabGeometry  # noqa: E402
 
 ALGO_BYTES_PER_POINT = 16.0   # read p, pp, v2 + write pp -- the ONE-step-per-pass byte model
 MIN_BYTES_PER_POINT_PER_LAUNCH = 20.0   # what any launch of the forward kernels must move: read u^n, u^{n-1}, v2 (12 B), write two fields (8 B)
@@ -183,12 +183,16 @@ def reference_sibling_cpu(m, nti):
                       f"(dpct_gpu_rtm_domain_division/src, g++ -O3 as its Makefiles build them: oracle/_ref/libref_dd.so), single thread, {dt:.1f} s"}
 
 
-def timed_windows(window, sync_all, world, dev, max_windows=400):
+MAX_WINDOWS = [400]      # --max-windows: debugging aid (a short, fixed sequence of shots)
+
+
+def timed_windows(window, sync_all, world, dev, max_windows=None):
     """Times `window()` (EXACTLY K steps, enqueue only) bracketed by barrier + synchronize on both sides, max over ranks; repeats the window
     until MIN_TIMED_SECONDS have been measured and returns (median wall seconds, median device ms between HIP events, windows).  A 20-step
     window at 8192^2 lasts 2.6 ms -- shorter than the clock ramp and than anything that samples the GPU; its median over ~100 windows equals
     what a 1000-step window gives."""
     import torch.distributed as dist
+    max_windows = min(max_windows or MAX_WINDOWS[0], MAX_WINDOWS[0])
     walls, devs = [], []
     total = 0.0
     while True:
@@ -229,14 +233,70 @@ def synthetic_velocity_rows(n, row0, rows, device):
     return v * v
 
 
-def cpu_baseline(n, seconds_target=12.0):
-    """The oracle's fused loop on the same grid size, one thread and all host threads, ~10-20 s per leg, in a process of its own
-    (oracle/cpu_baseline.py) so that torch's thread pool does not compete for the cores."""
+def cpu_baseline(n, seconds_target=12.0, rtm=False):
+    """The oracle's fused loop on the same grid size (rtm: one RTM shot through its reference-shaped passes on an n x n grid), one thread and
+    all host threads, ~10-20 s per leg, in a process of its own (oracle/cpu_baseline.py) so that torch's thread pool does not compete for the cores."""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), str(n), str(seconds_target)], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py")] + (["rtm"] if rtm else []) + [str(n), str(seconds_target)],
+                       capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("cpu_baseline failed: " + r.stderr[-2000:])
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def forward_line(n, K, W, dev, numerics=0, init="noise"):
+    """A compact forward-loop measurement on one GPU (the headline workload at another size): K steps per window after W warm-up steps from
+    the seeded-noise start, median window, HIP-event launch time, roofline from profiles/traffic.json when it holds this size and build."""
+    nt = K + W
+    ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=dev.index or 0, numerics=numerics)
+    pitch = ctx.pitch
+    v2 = torch.zeros((n, pitch), device=dev)
+    v2[:, :n] = synthetic_velocity_rows(n, 0, n, dev)
+    srce = torch.from_numpy(F.ricker_wavelet(nt, DT, FPEAK)).to(dev)
+    bufs = [torch.zeros((n, pitch), device=dev) for _ in range(4)]
+    if init == "noise":
+        g = torch.Generator(device=dev)
+        g.manual_seed(0x5EED0001)
+        for b_ in bufs[:2]:
+            b_[:, :n] = 1e-3 * torch.randn((n, n), device=dev, generator=g)
+    ptrs = [b.data_ptr() for b in bufs]
+    stream = torch.cuda.Stream()
+    roles = {"ip": 0, "ipp": 1}
+
+    def run(it0, nsteps):
+        roles["ip"], roles["ipp"] = ctx.dev_steps2(ptrs, v2.data_ptr(), srce.data_ptr(), n // 2, n // 2, it0, nsteps, it0 > 0, roles["ip"], roles["ipp"],
+                                                   stream=stream.cuda_stream)
+
+    torch.cuda.synchronize()
+    run(0, W)
+    stream.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def window():
+        e0.record(stream)
+        run(W, K)
+        e1.record(stream)
+        while not e1.query():
+            pass
+        stream.synchronize()
+        return e0.elapsed_time(e1)
+
+    wall, dev_ms, nwin = timed_windows(window, torch.cuda.synchronize, 1, dev)
+    newest = bufs[roles["ipp"]]
+    ok = bool(torch.isfinite(newest).all().item()) and float(newest.abs().max().item()) > 0.0
+    spl = ctx.steps_per_pass()
+    rem = K % spl
+    launches = K // spl + (rem // 2 + rem % 2 if ctx.two_step_active() else rem)
+    launch_s = dev_ms * 1e-3 / launches
+    prof = offline_counters("forward-fast" if numerics else "forward", n, spl)
+    traffic = prof["hbm_bytes_per_launch"] if prof else None
+    min_bytes = (ALGO_BYTES_PER_POINT if spl == 1 else MIN_BYTES_PER_POINT_PER_LAUNCH) * n * n
+    basis = traffic if traffic else min_bytes
+    return {"value": round(n * n * K / wall / 1e9, 3), "unit": "Gpoints/s", "ms_per_step": round(wall * 1e3 / K, 6), "steps": K, "warmup": W, "windows": nwin,
+            "grid": [n, n], "numerics": "fast" if numerics else "exact", "result_finite_nonzero": ok,
+            "roofline": {"bound": "hbm", "achieved": round(basis / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(basis / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "basis": "measured HBM-side bytes per launch" if traffic else "minimum bytes one launch must move",
+                         "traffic_source": traffic_source_note(prof), "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": spl}}
 
 
 def run_model_workload(args):
@@ -457,10 +517,10 @@ def run_rtm_slab_workload(args):
     into x slabs over the N ranks: K forward steps (fd_forward, fd-code.cu:259-267), the snapshot hand-over, then K backward iterations
     with source-field reconstruction, receiver injection and imaging (fd_back, fd-code.cu:302-339), halo exchanges of two / four fields
     overlapped with the interior rows.  A "step" is one time index of the shot = three field updates; value = 3 n^2 K / wall.
-    N = 1 runs the same driver on one slab (the whole grid).  --backend nccl: everything inside libfdwave.so over RCCL (fdw_slabs_*);
-    --backend gloo: the Python harness (decomp.SlabForward / SlabBack), ranks may share one GPU.  The image gathered from the slabs is
-    compared bitwise with a single-domain run on rank 0 unless --no-check."""
-    from parallel_finite_difference_computation_amd.decomp import HipSlabBackStepper, SlabBack, slab_bounds
+    N = 1 runs the same driver on one slab (the whole grid).  Everything runs inside libfdwave.so (fdw_slabs_*): --backend nccl over RCCL, one
+    rank per GPU; --backend shm over the library's process transport, ranks may share one GPU (rehearsals).  The image gathered from the
+    slabs is compared bitwise with a single-domain run on rank 0 unless --no-check."""
+    from parallel_finite_difference_computation_amd.decomp import slab_bounds
     rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and not (world == 1 and args.gpus == 1):
         if world == 1:
@@ -479,8 +539,8 @@ def run_rtm_slab_workload(args):
     nx = n - 2 * NB
     gz = NB + 3
     sx, sz = n // 2, NB + 2
-    c_driver = args.backend in ("nccl", "shm")
-    mk = dict(compat=False)
+    c_driver = True
+    NUM = 1 if args.numerics == "fast" else 0
     srce = torch.from_numpy(F.ricker_wavelet(nt, DT, FPEAK)).to(dev)
     gsmp = torch.Generator(device=dev)
     gsmp.manual_seed(0x5EED0005)
@@ -488,18 +548,13 @@ def run_rtm_slab_workload(args):
 
     def make_rank(comm_, geom_world, geom_rank):
         """Driver state of one rank: fields with the decomposition-independent noise start, v2, image."""
-        if c_driver:
-            sl = F.Slabs(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, comm=comm_, compat=False, ksteps=args.ksteps, device=local_rank)
-            g = SlabGeometry(geom_rank, geom_world, n, ORDER // 2, sl.ksteps)
-            pitch, nbuf, ctx = sl.pitch, sl.nbuf, None
-        else:
-            k = args.ksteps if args.ksteps > 0 else 4
-            g = SlabGeometry(geom_rank, geom_world, n, ORDER // 2, k if geom_world > 1 else 1)
-            ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank, slab=(g.x_off, g.nxl) if geom_world > 1 else None)
-            sl, pitch, nbuf = None, ctx.pitch, 2
-        nfb, nrb = sl.back_buffers() if c_driver else (2, 2)
+        sl = F.Slabs(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, comm=comm_, compat=False, ksteps=args.ksteps, device=local_rank, numerics=NUM)
+        g = SlabGeometry(geom_rank, geom_world, n, ORDER // 2, sl.ksteps)
+        assert (g.x_off, g.nxl, g.o0, g.o1) == (sl.x_off, sl.nxl, sl.own0, sl.own1)
+        pitch, nbuf = sl.pitch, sl.nbuf
+        nfb, nrb = sl.back_buffers()
         nsrc = max(nbuf, nfb)                                                                  # forward buffers double as the backward loop's source-field buffers
-        st = dict(sl=sl, ctx=ctx, g=g, pitch=pitch, nsrc=nsrc)
+        st = dict(sl=sl, g=g, pitch=pitch, nsrc=nsrc)
         st["fld"] = [torch.zeros((g.nxl, pitch), device=dev) for _ in range(nsrc + nrb)]       # ... + the receiver buffers
         gen = torch.Generator(device=dev)
         for f_, seed in ((st["fld"][0], 0x5EED0001), (st["fld"][1], 0x5EED0002)):
@@ -509,40 +564,23 @@ def run_rtm_slab_workload(args):
         st["v2"][:, :n] = synthetic_velocity_rows(n, g.x_off, g.nxl, dev)
         st["img"] = torch.zeros((g.nxl, pitch), device=dev)
         st["nbuf"], st["ip"], st["ipp"] = nbuf, 0, 1
-        if not c_driver:
-            st["fw"] = SlabForward(g, HipSlabStepper(ctx), st["fld"][:2], st["v2"], srce, sx, sz, overlap=not args.no_overlap)
         return st
 
     def shot(st, nsteps):
         """forward nsteps, snapshot hand-over, backward nsteps with imaging (enqueue; the caller synchronises)."""
         fld, rcv = st["fld"], st["fld"][st["nsrc"]:]
-        if c_driver:
-            sl = st["sl"]
-            st["ip"], st["ipp"] = sl.dev_forward([f_.data_ptr() for f_ in fld[:st["nbuf"]]], st["v2"].data_ptr(), srce.data_ptr(), sx, sz, 0, nsteps, True,
-                                                 st["ip"], st["ipp"])
-            sl.taper_finalize(fld[st["ip"]].data_ptr())                               # the damped d_p the reference hands over (R:285)
-            with torch.cuda.stream(torch.cuda.ExternalStream(sl.stream)):
-                rcv[0].zero_()
-                rcv[1].zero_()                                                        # R:513-514
-            sl.dev_back([f_.data_ptr() for f_ in fld[:st["nsrc"]]], [r_.data_ptr() for r_ in rcv], st["v2"].data_ptr(), samples.data_ptr(),
-                        gz, st["img"].data_ptr(), 0, nsteps, role=(st["ip"], st["ipp"], 0, 1))
-        else:
-            fw = st["fw"]
-            fw.it = 0
-            fw.run(nsteps)
-            fw.synchronize()
-            st["ctx"].dev_taper_finalize(fw.d_p.data_ptr())
+        sl = st["sl"]
+        st["ip"], st["ipp"] = sl.dev_forward([f_.data_ptr() for f_ in fld[:st["nbuf"]]], st["v2"].data_ptr(), srce.data_ptr(), sx, sz, 0, nsteps, True,
+                                             st["ip"], st["ipp"])
+        sl.taper_finalize(fld[st["ip"]].data_ptr())                               # the damped d_p the reference hands over (R:285)
+        with torch.cuda.stream(torch.cuda.ExternalStream(sl.stream)):
             rcv[0].zero_()
-            rcv[1].zero_()
-            torch.cuda.synchronize()
-            bk = SlabBack(st["g"], HipSlabBackStepper(st["ctx"]), (fw.d_p, fw.d_pp), rcv, st["v2"], samples, gz, st["img"], nt, overlap=not args.no_overlap)
-            bk.run(nsteps)
-            bk.synchronize()
-            st["bk"] = bk
+            rcv[1].zero_()                                                        # R:513-514
+        sl.dev_back([f_.data_ptr() for f_ in fld[:st["nsrc"]]], [r_.data_ptr() for r_ in rcv], st["v2"].data_ptr(), samples.data_ptr(),
+                    gz, st["img"].data_ptr(), 0, nsteps, role=(st["ip"], st["ipp"], 0, 1))
 
     def sync(st):
-        if c_driver:
-            st["sl"].synchronize()
+        st["sl"].synchronize()
         torch.cuda.synchronize()
 
     comm = None
@@ -593,6 +631,7 @@ def run_rtm_slab_workload(args):
                 dist.recv(parts[r], src=r)
             full = torch.cat(parts).to(dev)
             ref = make_rank(None, 1, 0)                    # the same driver on ONE slab = the whole grid, same sequence of shots
+            torch.cuda.synchronize()                       # its fields were filled on torch's stream; the library's streams are non-blocking and would not wait for that
             shot(ref, W)
             sync(ref)
             for _ in range(nwin):
@@ -600,6 +639,13 @@ def run_rtm_slab_workload(args):
                 sync(ref)
             same = bool(torch.equal(full, ref["img"][:, :n]))
             print(f"[check] decomposed image ({world} slabs) == single domain, bitwise: {same}", file=sys.stderr, flush=True)
+            if not same:      # where: rows / columns / slabs of the differing cells (a halo that came late shows up next to a band edge)
+                bad = (full != ref["img"][:, :n]).nonzero()
+                rws, cls = bad[:, 0], bad[:, 1]
+                edges = [b0 for (b0, _b1) in slab_bounds(n, world)]
+                print(f"[check] {bad.shape[0]} cells differ: rows {int(rws.min())}..{int(rws.max())}, columns {int(cls.min())}..{int(cls.max())}; band edges at rows {edges}; "
+                      f"max |diff| {float((full - ref['img'][:, :n]).abs().max()):.3e} of max {float(ref['img'].abs().max()):.3e}; "
+                      f"rows with differences per band: {[int(((rws >= b0) & (rws < b1)).sum()) for (b0, b1) in slab_bounds(n, world)]}", file=sys.stderr, flush=True)
             check = "image bitwise equal to a single-domain run of the same shots" if same else "image DIFFERS from the single-domain run"
             check_failed = not same        # the line is still printed (flagged), the exit code says so at the end
         else:
@@ -621,6 +667,7 @@ def run_rtm_slab_workload(args):
         sl, fld, rcv = me["sl"], me["fld"], me["fld"][me["nsrc"]:]
         ext = torch.cuda.ExternalStream(sl.stream)
         scratch_img = torch.zeros_like(me["img"])
+        torch.cuda.synchronize()                           # filled on torch's stream; the library's streams are non-blocking
 
         def back_ms(iters):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -646,7 +693,7 @@ def run_rtm_slab_workload(args):
                                       f"with imaging, {me['g'].ksteps if world > 1 else 0} steps per halo exchange", "grid": [n, n], "order": ORDER,
                           "parallelism": f"slab{world}" if world > 1 else "single"},
                "result_finite_nonzero": finite and nonzero,
-               "halo_exchange": (HALO_PATHS[comm.kind] if c_driver else "torch.distributed gloo (single-GPU rehearsal harness)") if world > 1 else None,
+               "halo_exchange": HALO_PATHS[comm.kind] if world > 1 else None,
                "decomposition_check": check,
                "rccl_ranks": comm.world if (comm is not None and comm.kind == "rccl") else None, "comm_ranks": comm.world if comm is not None else world,
                "exposed_comm_fraction": exposed["value"] if exposed else None, "exposed_comm": exposed,
@@ -680,11 +727,12 @@ def run_rtm_slab_workload(args):
                                                              "note": "forward 16 + backward 44 B/point per time index over the wall time (the model of the one-step kernels)"}}
             if prof and prof.get("valu_busy") is not None:
                 out["roofline"]["issue"] = {"valu_busy": prof["valu_busy"], "salu_per_valu": prof.get("salu_per_valu"), "source": prof.get("sq_source")}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(min(n, 2048), 8.0, rtm=True)      # bounded sample: a 2048^2 grid, iterations sized for ~8 s per leg
         print(json.dumps(out), flush=True)
-    if c_driver:
-        me["sl"].close()
-        if comm is not None:
-            comm.close()
+    me["sl"].close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
     if not (finite and nonzero):
@@ -723,20 +771,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rest-line", action="store_true", help="forward workload, N = 1: skip the extra measurement from BASELINE.md's zero initial fields")
     ap.add_argument("--no-overlap", action="store_true")
-    ap.add_argument("--backend", default="nccl", choices=("nccl", "shm", "gloo"),
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "shm"),
                     help="N > 1: nccl = halo exchange over RCCL inside libfdwave.so, one rank per GPU (default); shm = the same C drivers over the "
-                         "library's process transport (shared-memory staging), ranks may share one GPU (rehearsals); gloo = the Python test harness")
-    ap.add_argument("--check", action="store_true", help="N > 1: compare the decomposed result with a single-domain run on rank 0 (default with --backend nccl)")
-    ap.add_argument("--no-check", action="store_true", help="N > 1, --backend nccl: skip that comparison")
+                         "library's process transport (shared-memory staging), ranks may share one GPU (rehearsals on a one-GPU box)")
+    ap.add_argument("--check", action="store_true", help="N > 1: compare the decomposed result with a single-domain run on rank 0, bitwise (always on; kept for old command lines)")
+    ap.add_argument("--no-check", action="store_true", help="N > 1: skip that comparison")
     ap.add_argument("--no-exposed", action="store_true", help="N > 1, --backend nccl: skip the re-timing with the transfers off (exposed_comm_fraction)")
     ap.add_argument("--numerics", choices=["exact", "fast"], default="exact",
                     help="exact (default, what `value` always reports in the default run): the reference's arithmetic operation for operation, bit-identical "
                          "to the oracle; fast: fdw_params.numerics = FDW_NUMERICS_FAST (symmetric sums + fused multiply-adds in the Laplacian, within "
                          "1e-5 of exact) for the whole run -- profiling and scaling runs of that mode; the default run prints it beside the headline")
+    ap.add_argument("--max-windows", type=int, default=400, help="cap on the repetitions of the timed window (debugging aid: a short, fixed sequence)")
+    ap.add_argument("--no-extra", action="store_true", help="forward workload, N = 1, default size: skip the extra 4096^2 / 1000-step line (BASELINE.json configs[1])")
     ap.add_argument("--no-fast-line", action="store_true", help="forward workload, N = 1: skip the extra measurement in FAST numerics")
     ap.add_argument("--init", choices=["noise", "rest"], default="noise",
                     help="initial wavefield: seeded noise (default; every cache line carries real data) or at rest (zeros + source)")
     args = ap.parse_args()
+    MAX_WINDOWS[0] = max(1, args.max_windows)
     if os.environ.get("FDW_BENCH_POISON") == "1":
         poison_free_memory()
     if args.workload == "rtm-slab":
@@ -769,7 +820,7 @@ def main():
         # control plane (barriers, the max over ranks of the window time, gathering the slabs for the check): a gloo group on the host.
         # The data plane -- the halo rows -- travels inside libfdwave.so: over RCCL / xGMI (--backend nccl, the default, one rank per GPU) or,
         # for rehearsals of several ranks on ONE GPU (RCCL refuses duplicate devices), through the library's process transport (--backend shm:
-        # the same C drivers, halo blocks staged through shared memory).  --backend gloo runs the Python test harness instead.
+        # the same C drivers, halo blocks staged through shared memory).
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n, K, W = args.size, args.steps, args.warmup
@@ -777,13 +828,15 @@ def main():
     NUM = 1 if args.numerics == "fast" else 0
     srce = torch.from_numpy(F.ricker_wavelet(nt, DT, FPEAK)).to(dev)
     sx, sz = n // 2, n // 2
-    c_driver = (world > 1 and args.backend in ("nccl", "shm")) or os.environ.get("FDW_FORCE_SLAB_DRIVER") == "c"      # the latter: the multi-GPU code path on one rank (tests)
-    slabs = comm = harness_group = None
+    c_driver = world > 1 or os.environ.get("FDW_FORCE_SLAB_DRIVER") == "c"      # the latter: the multi-GPU code path on one rank (tests)
+    slabs = comm = None
     use_pipe = False
+    rccl_fallback = None
     if c_driver:
         # the communicator: ncclGetUniqueId on rank 0, the bytes to every rank through the control-plane group, ncclCommInitRank (one rank per GPU),
         # and one message to the own rank as a check.  Should librccl not be usable from the C library on this machine, every rank falls back
-        # -- together -- to the Python harness over torch.distributed's own RCCL group rather than lose the measurement.
+        # -- together -- to the library's process transport (halo blocks staged through shared memory: slow, flagged in the line) rather than
+        # lose the measurement altogether.
         err = None
         uid = [None]
         if args.backend == "shm" and world > 1:
@@ -804,17 +857,16 @@ def main():
                     err = e
             else:
                 err = err or RuntimeError("rank 0 could not create the RCCL unique id")
-        bad = torch.tensor([1.0 if err is not None else 0.0])
-        if world > 1:
-            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        if bad.item() > 0:
-            print(f"[bench] rank {rank}: RCCL inside libfdwave.so is not usable here ({err}); falling back to the torch.distributed harness", file=sys.stderr, flush=True)
-            if comm is not None:
-                comm.close()
-            comm, c_driver = None, False
+            bad = torch.tensor([1.0 if err is not None else 0.0])
             if world > 1:
-                harness_group = dist.new_group(backend="nccl")
-    if c_driver:
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if bad.item() > 0:
+                print(f"[bench] rank {rank}: RCCL inside libfdwave.so is not usable here ({err}); falling back to the library's process transport (shared-memory staging)",
+                      file=sys.stderr, flush=True)
+                if comm is not None:
+                    comm.close()
+                rccl_fallback = str(err) if err is not None else "another rank could not open RCCL"
+                comm = shm_communicator(rank, world, local_rank, n) if world > 1 else None
         if args.pipe != "auto":
             os.environ["FDW_SLAB_PIPE"] = "1" if args.pipe == "on" else "0"
         if args.no_overlap:
@@ -825,21 +877,8 @@ def main():
         assert (geom.x_off, geom.nxl, geom.o0, geom.o1) == (slabs.x_off, slabs.nxl, slabs.own0, slabs.own1)
         ctx, pitch = None, slabs.pitch
     else:
-        if world > 1 and args.ksteps <= 0:
-            # One exchange costs the host a few hundred us of Python enqueue whatever its size, so make a
-            # cycle last >= ~500 us of GPU time: k = 500 us / (slab points / ~350 Gpt/s), clamped to [2, 16].
-            t_step_us = (n / world) * n / 350e9 * 1e6
-            args.ksteps = int(max(2, min(16, -(-500.0 // t_step_us))))
-        if world > 1 and args.pipe != "off":
-            # decide on the slab size every rank has in common (all ranks must take the same path): rows of the thinnest slab
-            probe = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank, slab=(0, n // world), numerics=NUM)
-            use_pipe = args.pipe == "on" or probe.steps_per_pass() == 4
-            del probe
-            if use_pipe:
-                args.ksteps = max(4, min(16, 4 * -(-args.ksteps // 4)))      # whole passes of four steps
-        geom = SlabGeometry(rank, world, n, ORDER // 2, args.ksteps if world > 1 else 1)
-        ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank,
-                       slab=(geom.x_off, geom.nxl) if world > 1 else None, numerics=NUM)
+        geom = SlabGeometry(0, 1, n, ORDER // 2, 1)
+        ctx = F.FDWave(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, compat=False, device=local_rank, numerics=NUM)
         if os.environ.get("FDW_XCHUNK"):      # tuning experiments only
             ctx.set_tuning(xchunk=int(os.environ["FDW_XCHUNK"]))
         pitch = ctx.pitch
@@ -864,7 +903,7 @@ def main():
         return fl
 
     rest_line = fast_line = None
-    if world == 1 and not c_driver and not os.environ.get("FDW_FORCE_SLAB_DRIVER"):
+    if not c_driver:
         # One GPU: the library's forward loop over four rotating buffers (fdw_dev_steps2): pairs of time steps go
         # through the two-step kernel (temporal blocking) where it pays, everything enqueued by ONE library call.
         skew = int(os.environ.get("FDW_ALLOC_SKEW", "0"))     # tuning experiments only: bytes of padding between the field buffers
@@ -985,7 +1024,7 @@ def main():
             if f_prof and f_prof.get("valu_busy") is not None:
                 fast_line["roofline"]["issue"] = {"valu_busy": f_prof["valu_busy"], "salu_per_valu": f_prof.get("salu_per_valu"), "source": f_prof.get("sq_source")}
             del fctx
-    elif c_driver:
+    else:
         # N GPUs, one rank each: the whole K-step window -- passes, boundary strips, halo exchange over RCCL on the communication stream,
         # interior rows beside the transfer -- is enqueued by ONE call into the C library (fdw_slabs_dev_forward)
         fields = slab_noise_fields(slabs.nbuf)
@@ -1007,26 +1046,6 @@ def main():
 
         wall, dev_ms, nwin = timed_windows(window, sync_all, world, dev)
         newest = fields[roles["ipp"]][geom.g_lo:geom.nxl - geom.g_hi]
-    else:
-        fields = slab_noise_fields(4 if use_pipe else 2)
-        fw = SlabForward(geom, HipSlabStepper(ctx), fields, v2, srce, sx, sz, group=harness_group, overlap=not args.no_overlap, pipe_ctx=ctx if use_pipe else None)
-        torch.cuda.synchronize()       # fields were filled on torch's default stream; the driver's streams do not wait for it
-        fw.run(W)
-        fw.synchronize()       # also forces torch's lazy creation of both streams outside the timed region
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-
-        def window():
-            fw.it = W              # the source samples of the timed window every time (srce holds W + K of them)
-            e0.record(fw.compute)
-            fw.run(K)
-            e1.record(fw.compute)
-            while not e1.query():
-                pass
-            fw.synchronize()
-            return e0.elapsed_time(e1)
-
-        wall, dev_ms, nwin = timed_windows(window, sync_all, world, dev)
-        newest = fw.owned(fw.d_pp)
     finite = bool(torch.isfinite(newest).all().item()) and float(newest.abs().max().item()) > 0.0
     if world > 1:
         f = torch.tensor([1.0 if finite else 0.0])
@@ -1035,7 +1054,7 @@ def main():
 
     check = None
     check_failed = False
-    if world > 1 and (args.check or (args.backend in ("nccl", "shm") and not args.no_check)):
+    if world > 1 and not args.no_check:
         # the decomposed field against a single-domain run of the same step sequence (warm-up, then `nwin` windows that replay the
         # source samples W .. W+K-1) on rank 0, bitwise: a halo that arrives late or not at all cannot hide behind a plausible number
         own = newest[:, :n].contiguous().cpu()
@@ -1096,12 +1115,10 @@ def main():
             "result_finite_nonzero": finite,
         }
         if world > 1:
-            out["halo_exchange"] = (HALO_PATHS[comm.kind] if c_driver
-                                    else ("torch.distributed nccl P2P (fallback harness: RCCL was not usable from libfdwave.so)" if harness_group is not None
-                                          else f"torch.distributed {args.backend} (single-GPU rehearsal harness)"))
+            out["halo_exchange"] = HALO_PATHS[comm.kind] + (f" -- FALLBACK: RCCL was not usable from libfdwave.so ({rccl_fallback})" if rccl_fallback else "")
             out["decomposition_check"] = check
-            out["rccl_ranks"] = comm.world if (c_driver and comm is not None and comm.kind == "rccl") else None
-            out["comm_ranks"] = comm.world if (c_driver and comm is not None) else world
+            out["rccl_ranks"] = comm.world if comm.kind == "rccl" else None
+            out["comm_ranks"] = comm.world
             out["exposed_comm_fraction"] = exposed["value"] if exposed else None
             out["exposed_comm"] = exposed
             out["launched_by"] = "bench.py itself (child processes)" if os.environ.get("FDW_BENCH_SELF_LAUNCHED") else "an external launcher (torch.distributed.run)"
@@ -1109,6 +1126,13 @@ def main():
             out["baseline_md_initial_condition"] = rest_line
         if fast_line is not None:
             out["fast_numerics"] = fast_line
+        if world == 1 and not c_driver and n == 8192 and not args.no_extra:
+            # BASELINE.json's second configuration verbatim -- 4096^2 fp32, 1000 steps, one MI355X -- recorded by the same invocation, so that the
+            # driver's one default run holds it too (the headline stays the 8192^2 grid the north-star target is quoted on)
+            del bufs
+            torch.cuda.empty_cache()
+            out["extra"] = {"baseline_config_2": dict(forward_line(4096, 1000, 50, dev, numerics=NUM, init=args.init),
+                                                      config="2D 8th-order acoustic stencil, 4096^2 fp32, 1000 steps, 1 x MI355X (BASELINE.json configs[1])")}
         out["numerics"] = "fast" if NUM else "exact"
         if NUM:
             out["config"]["workload"] += ", FAST numerics (symmetric sums + fused multiply-adds in the Laplacian; <= 1e-5 from the reference's arithmetic)"

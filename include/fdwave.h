@@ -230,9 +230,18 @@ void fdw_mod_taper_tables(int nxb, int nzb, float fac, float *taper_x, float *ta
  *                 FDW_ENOMEM when they do not fit), the receiver pass injects sample nt-it of every trace of shot `is` -- read from the
  *                 WHOLE gather dobs[ns][nx][nt] of n_floats floats exactly as the reference indexes it, i.e. one sample past the trace at
  *                 it = 0 (a sample past the end of the file counts as 0) and with its nzb row offset (rtm_main.cpp:203) -- and the image
- *                 accumulates swf[nt-it-1] * rwf[it] in iteration order (same sums as rtm_main.cpp:224-230).  imloc[nx][nz] is overwritten. */
+ *                 accumulates swf[nt-it-1] * rwf[it] in iteration order (same sums as rtm_main.cpp:224-230).  imloc[nx][nz] is overwritten.
+ *                 When the nt fields do not fit -- the budget of fdw_set_store_budget (or FDW_STORE_BUDGET_MB), else what hipMalloc grants --
+ *                 the source pass CHECKPOINTS: it keeps the pair of fields every m-th step starts from, and the receiver pass recomputes
+ *                 one segment of m fields at a time from its pair (2 ceil(nt/m) + m + 1 fields, least near m = sqrt(2 nt); one more forward
+ *                 pass of launches).  The recomputation repeats the same launches on the same inputs: the image is bit-identical to the
+ *                 unconstrained run.  FDW_ENOMEM only when not even that fits.
+ * fdw_set_store_budget  bytes the stored source fields may occupy (0 = no limit of our own); fdw_store_segments: how many segments the last
+ *                 fdw_rtm_stored_shot was cut into (1 = every field was kept). */
 int fdw_rtm_stored_shot(fdw_ctx *ctx, const float *vel2, int sx, int sz, int gz, const float *srce, int nt, const float *dobs,
                         size_t n_floats, int is, float *imloc);
+int fdw_set_store_budget(fdw_ctx *ctx, size_t bytes);
+int fdw_store_segments(const fdw_ctx *ctx);
 
 /* ---- image post-processing -----------------------------------------------------------------
  * fdw_image_laplacian  the reference's offline filter models/3lay_mod/laplace.f90:25-29 (dir.image -> dir.imalap): second-order

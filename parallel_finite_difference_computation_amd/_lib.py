@@ -60,6 +60,8 @@ SIGNATURES = [
     ("fdw_image_laplacian", C.c_int, [C.c_int, f32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p]),
     ("fdw_image_compare", C.c_int, [C.c_int, f32p, f32p, C.c_size_t, vp, C.POINTER(C.c_double), C.c_int]),
     ("fdw_rtm_stored_shot", C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_size_t, C.c_int, f32p]),
+    ("fdw_set_store_budget", C.c_int, [vp, C.c_size_t]),
+    ("fdw_store_segments", C.c_int, [vp]),
     ("fdw_border_draws", C.c_longlong, [C.c_int] * 4),
     ("fdw_model_resident", C.c_int, [vp, f32p]),
     ("fdw_dev_extendvel_linear", C.c_int, [vp, C.c_ulonglong, vp]),

@@ -269,6 +269,18 @@ class FDWave:
         check(lib().fdw_rtm_stored_shot(self._h, _f32(vel2, (self.nxe, self.nze)), sx, sz, gz, srce, srce.size, dobs, dobs.size, shot, imloc))
         return imloc
 
+    def set_store_budget(self, nbytes):
+        """Bytes the stored source fields of rtm_stored_shot may occupy (0: no limit of our own).  Below nt + 1 fields the shot checkpoints and
+        recomputes (fdwave.h); the image stays bit-identical."""
+        check(lib().fdw_set_store_budget(self._h, int(nbytes)))
+
+    def store_segments(self):
+        """Segments the last rtm_stored_shot was cut into (1: every field was kept)."""
+        return int(lib().fdw_store_segments(self._h))
+
+    def field_bytes(self):
+        return int(lib().fdw_field_bytes(self._h))
+
     def dev_model_steps(self, d_p, d_pp, d_v2, d_srce, sx, sz, gz, d_rec, it0, nsteps, stream=None):
         check(lib().fdw_dev_model_steps(self._h, d_p, d_pp, d_v2, d_srce, sx, sz, gz, d_rec, it0, nsteps, stream))
 

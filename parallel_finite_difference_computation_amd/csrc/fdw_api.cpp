@@ -94,6 +94,8 @@ struct fdw_ctx {
     int no_fused_back = 0;   // experiments / tests: backward iterations as two launches (source step, receiver step) -- FDW_NO_FUSED_BACK=1
     int no_back_pipe = 0;    // experiments / tests: no wave-pipeline passes in the backward loop -- FDW_NO_BACK_PIPE=1
     int no_back_fused = 0;   // experiments / tests: the backward pipeline as two passes (source field, receiver field) instead of the fused kernel -- FDW_NO_BACK_FUSED=1
+    size_t store_budget = 0; // fdw_rtm_stored_shot: bytes the stored source fields may take (0: whatever the device grants); fdw_set_store_budget
+    int store_segments = 0;  // ... segments the last such shot was cut into (1: every field kept)
 };
 
 static size_t field_elems(const fdw_ctx* c) { return (size_t)c->nxl * (size_t)c->pitch; }
@@ -1227,6 +1229,14 @@ extern "C" int fdw_shot(fdw_ctx* c, const float* v2, int sx, int sz, int gz, con
 // ------------------------------------------------------------------------------------------------
 // tuning / introspection
 // ------------------------------------------------------------------------------------------------
+extern "C" int fdw_set_store_budget(fdw_ctx* c, size_t bytes)
+{
+    if (!c) return fail(FDW_EINVAL, "ctx is NULL");
+    c->store_budget = bytes;
+    return FDW_OK;
+}
+extern "C" int fdw_store_segments(const fdw_ctx* c) { return c ? c->store_segments : 0; }
+
 extern "C" int fdw_set_tuning(fdw_ctx* c, int xchunk, int wz, int use_generic, int prefetch, int two_step)
 {
     if (!c) return fail(FDW_EINVAL, "ctx is NULL");
@@ -1334,14 +1344,6 @@ extern "C" int fdw_rtm_stored_shot(fdw_ctx* c, const float* vel2, int sx, int sz
     int rc;
     if ((rc = ensure_work_buffers(c, 2, true))) return rc;
     const size_t nx = c->nx, fe = field_elems(c);
-    // the source wavefield of every step (rtm_main.cpp:177-181 keeps the interior; whole pitched fields here so that the imaging
-    // epilogue of the step kernel can read them like any other field)
-    float* d_swf = nullptr;
-    if (nt > 0) {
-        hipError_t e = hipMalloc((void**)&d_swf, fe * (size_t)nt * sizeof(float));
-        if (e != hipSuccess) return fail(FDW_ENOMEM, "the %d stored source fields need %zu bytes: %s", nt, fe * (size_t)nt * sizeof(float), hipGetErrorString(e));
-    }
-    struct Free { float* p; ~Free() { if (p) (void)hipFree(p); } } guard{d_swf};
     // receiver samples as the reference indexes them: step it reads dobs[is][ix][nt - it]
     std::vector<float> rows(std::max<size_t>(nx * (size_t)nt, 1));
     for (int it = 0; it < nt; it++)
@@ -1353,27 +1355,97 @@ extern "C" int fdw_rtm_stored_shot(fdw_ctx* c, const float* vel2, int sx, int sz
     HIP_TRY(hipMemcpy(c->d_dobs, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
     if ((rc = upload_rows(c, c->d_v2, vel2, c->stream)) || (rc = upload_source(c, srce, nt))) return rc;
     float *d_p = c->fld[0], *d_pp = c->fld[1];
-    HIP_TRY(hipMemsetAsync(d_p, 0, fe * sizeof(float), c->stream));     // rtm_main.cpp:161-162
-    HIP_TRY(hipMemsetAsync(d_pp, 0, fe * sizeof(float), c->stream));
-    // The fields of the forward loop LIVE in the store: swf[it] = P of step it (rtm_main.cpp:177-181; an interior point is never damped, and the
-    // kernels damp on load), so step it reads p = swf[it], pp = swf[it-1] and writes the new field straight into swf[it+1] -- no copy per step
-    // (round 1 copied a whole field per step: 21 % of the device time of a 3lay_mod-sized shot).  P of step 0 and its predecessor are zero.
-    if (nt > 0) HIP_TRY(hipMemsetAsync(d_swf, 0, fe * (size_t)nt * sizeof(float), c->stream));      // step 0's P, and the padding columns of every slot
-    for (int it = 0; it < nt; it++) {
-        const float* p_in = d_swf + (size_t)it * fe;
-        float* pp_in = it > 0 ? d_swf + (size_t)(it - 1) * fe : d_pp;                  // only read (out is given)
-        float* out = it + 1 < nt ? d_swf + (size_t)(it + 1) * fe : d_p;                // the last new field is not stored by the reference either
-        rc = step_impl(c, FDW_MODE_DD_FWD, p_in, pp_in, c->d_v2, 0, c->nxl, 1, c->d_srce + it, sx, sz, nullptr, nullptr, c->stream, nullptr, 0, nullptr, out);
-        if (rc) return rc;
+    // The source wavefield of every step (rtm_main.cpp:177-181 keeps the interior; whole pitched fields here so that the imaging epilogue of
+    // the step kernel can read them like any other field): swf[it] = P of step it, it = 0 .. nt-1, swf[0] = 0.  The receiver pass consumes
+    // them LAST FIRST (iteration it images against swf[nt-it-1], rtm_main.cpp:224-230).
+    //   * They fit the store budget (fdw_set_store_budget; default: whatever hipMalloc grants): all nt fields are kept, one segment.
+    //   * They do not: CHECKPOINTING.  The steps are cut into S segments of m; the forward pass keeps, per segment, only the pair of fields it
+    //     starts from (2 S fields) and runs through ONE segment buffer of m + 1 fields; the receiver pass takes the segments last first and
+    //     recomputes each from its pair into that buffer before consuming it.  The recomputation is the same launches on the same inputs, so
+    //     every stored field -- and with it the image -- is bit-identical to the unconstrained run; the price is one more forward pass
+    //     (2 nt + nt launches instead of nt + nt).  Memory 2 S + m + 1 fields, least at m ~ sqrt(2 nt): 1 001 steps fit in 92 fields.
+    const size_t fbytes = fe * sizeof(float);
+    size_t budget_fields = c->store_budget ? c->store_budget / fbytes : (size_t)-1;
+    if (const char* e = getenv("FDW_STORE_BUDGET_MB")) budget_fields = (size_t)atoll(e) * ((size_t)1 << 20) / fbytes;
+    int m = std::max(nt, 1), S = 1;                       // segment length, segments
+    float *d_seg = nullptr, *d_ck = nullptr;
+    struct Free { float*& p; ~Free() { if (p) (void)hipFree(p); } } g1{d_seg}, g2{d_ck};
+    bool whole = (size_t)nt + 1 <= budget_fields;
+    const int forced_m = getenv("FDW_STORE_SEGMENT") ? atoi(getenv("FDW_STORE_SEGMENT")) : 0;      // tests: checkpoint with this segment length whatever fits
+    if (forced_m > 0 && forced_m < nt) whole = false;
+    if (whole && nt > 0 && hipMalloc((void**)&d_seg, fbytes * ((size_t)nt + 1)) != hipSuccess) {      // no budget given and the device says no: checkpoint into what is free
+        (void)hipGetLastError();
+        d_seg = nullptr;
+        whole = false;
+        size_t fr = 0, tot = 0;
+        HIP_TRY(hipMemGetInfo(&fr, &tot));
+        budget_fields = (size_t)(0.9 * (double)fr) / fbytes;
     }
-    HIP_TRY(hipMemsetAsync(d_p, 0, fe * sizeof(float), c->stream));     // rtm_main.cpp:187-189
-    HIP_TRY(hipMemsetAsync(d_pp, 0, fe * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_img, 0, fe * sizeof(float), c->stream));
-    for (int it = 0; it < nt; it++) {
-        rc = step_impl(c, FDW_MODE_DD_RECV, d_p, d_pp, c->d_v2, 0, c->nxl, 1, c->d_dobs + (size_t)it * nx, -1, gz,
-                       d_swf + (size_t)(nt - it - 1) * fe, c->d_img, c->stream);
-        if (rc) return rc;
-        std::swap(d_p, d_pp);
+    if (!whole && nt > 0) {
+        // the longest segment that fits: fewest restarts, same recomputation cost (one forward pass) whatever m is
+        int best = 0;
+        for (int mm = nt; mm >= 1; mm--)
+            if (2 * (size_t)((nt + mm - 1) / mm) + (size_t)mm + 1 <= budget_fields) { best = mm; break; }
+        if (forced_m > 0 && forced_m < nt) best = forced_m;
+        if (best == 0)
+            return fail(FDW_ENOMEM, "the stored source fields of %d steps need at least %d fields of %zu bytes with checkpointing (%d + 1 without); the store budget holds %zu",
+                        nt, (int)(2 * std::ceil(std::sqrt(nt / 2.0)) + std::ceil(std::sqrt(2.0 * nt)) + 1), fbytes, nt, budget_fields);
+        m = best;
+        S = (nt + m - 1) / m;
+        hipError_t e1 = hipMalloc((void**)&d_seg, fbytes * ((size_t)m + 1));
+        hipError_t e2 = e1 == hipSuccess ? hipMalloc((void**)&d_ck, fbytes * 2 * (size_t)S) : e1;
+        if (e1 != hipSuccess || e2 != hipSuccess) return fail(FDW_ENOMEM, "checkpointed store (%d segments of %d steps, %zu bytes per field): %s", S, m, fbytes, hipGetErrorString(e2));
+    }
+    c->store_segments = S;
+    auto seg = [&](int j) { return d_seg + (size_t)j * fe; };
+    auto ck = [&](int s, int which) { return d_ck + ((size_t)2 * s + which) * fe; };      // which 0: swf[s m - 1], 1: swf[s m]
+    // one segment of the forward loop: fields swf[s0 .. s0+len] into seg[0 .. len]; prev = swf[s0 - 1], seg[0] must hold swf[s0].
+    // Step it reads p = swf[it], pp = swf[it-1] and writes the new field straight into the next slot -- no copy per step.  (Cells a launch
+    // never stores -- the padding columns -- are zero in every slot from the memset below and stay so.)
+    auto run_segment = [&](int s0, int len, const float* prev) -> int {
+        for (int j = 0; j < len; j++) {
+            const int it = s0 + j;
+            float* pp_in = j > 0 ? seg(j - 1) : const_cast<float*>(prev);                  // only read (out is given)
+            int r = step_impl(c, FDW_MODE_DD_FWD, seg(j), pp_in, c->d_v2, 0, c->nxl, 1, c->d_srce + it, sx, sz, nullptr, nullptr, c->stream, nullptr, 0, nullptr, seg(j + 1));
+            if (r) return r;
+        }
+        return FDW_OK;
+    };
+    if (nt > 0) {
+        HIP_TRY(hipMemsetAsync(d_seg, 0, fbytes * ((size_t)m + 1), c->stream));          // swf[0] = 0 (rtm_main.cpp:161-162) and every padding column
+        HIP_TRY(hipMemsetAsync(d_pp, 0, fbytes, c->stream));                              // the field before step 0
+        if (d_ck) HIP_TRY(hipMemsetAsync(d_ck, 0, fbytes * 2 * (size_t)S, c->stream));
+        for (int s = 0; s < S; s++) {
+            const int s0 = s * m, len = std::min(m, nt - s0);
+            if (s > 0) HIP_TRY(hipMemcpyAsync(seg(0), ck(s, 1), fbytes, hipMemcpyDeviceToDevice, c->stream));
+            if ((rc = run_segment(s0, len, s > 0 ? ck(s, 0) : d_pp))) return rc;
+            if (s + 1 < S) {                              // what the next segment starts from: swf[s0 + m - 1], swf[s0 + m]
+                HIP_TRY(hipMemcpyAsync(ck(s + 1, 0), seg(m - 1), fbytes, hipMemcpyDeviceToDevice, c->stream));
+                HIP_TRY(hipMemcpyAsync(ck(s + 1, 1), seg(m), fbytes, hipMemcpyDeviceToDevice, c->stream));
+            }
+        }
+    }
+    HIP_TRY(hipMemsetAsync(d_p, 0, fbytes, c->stream));     // rtm_main.cpp:187-189
+    HIP_TRY(hipMemsetAsync(d_pp, 0, fbytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_img, 0, fbytes, c->stream));
+    float* d_zero = nullptr;                                // checkpointing: the zero field before step 0 (d_pp is a receiver field from here on)
+    struct Free g3{d_zero};
+    if (S > 1) {
+        if (hipMalloc((void**)&d_zero, fbytes) != hipSuccess) return fail(FDW_ENOMEM, "hipMalloc(%zu) failed", fbytes);
+        HIP_TRY(hipMemsetAsync(d_zero, 0, fbytes, c->stream));
+    }
+    int it = 0;
+    for (int s = S - 1; s >= 0 && nt > 0; s--) {
+        const int s0 = s * m, len = std::min(m, nt - s0);
+        if (s < S - 1) {                                    // (the last segment is still in the buffer from the forward pass)
+            HIP_TRY(hipMemcpyAsync(seg(0), s > 0 ? ck(s, 1) : d_zero, fbytes, hipMemcpyDeviceToDevice, c->stream));
+            if ((rc = run_segment(s0, len, s > 0 ? ck(s, 0) : d_zero))) return rc;
+        }
+        for (int j = len - 1; j >= 0; j--, it++) {          // receiver iteration `it` images against swf[nt - it - 1] = swf[s0 + j]
+            rc = step_impl(c, FDW_MODE_DD_RECV, d_p, d_pp, c->d_v2, 0, c->nxl, 1, c->d_dobs + (size_t)it * nx, -1, gz, seg(j), c->d_img, c->stream);
+            if (rc) return rc;
+            std::swap(d_p, d_pp);
+        }
     }
     if ((rc = image_to_host(c, imloc))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -11,9 +11,12 @@
 //          communication stream, ordered after the sender's stream by an event and held against the sender's next write by a second
 //          event -- the same dependencies a send in flight has.  Ranks may share one device (tests and rehearsals on a one-GPU box: RCCL
 //          refuses two ranks on one device) or sit on different devices of the node (peer copies over xGMI, no RCCL involved).
-//   shm    one rank per PROCESS without RCCL: halo blocks are staged through a POSIX shared-memory segment (device -> segment on the
-//          sender's stream, segment -> device on the receiver's), sequence numbers in the segment say when a block has arrived and when
-//          it has been taken.  A TEST TRANSPORT: it lets the slab drivers of fdw_slabs.cpp run as real processes whose streams know
+//   shm    one rank per PROCESS without RCCL: halo blocks are staged through a POSIX shared-memory segment.  The GPU only ever touches
+//          process-private pinned buffers: device -> private buffer on the sender's stream, then a host function behind that copy moves the
+//          block into the segment and publishes its sequence number; the receiver waits for the number, copies the block out of the segment
+//          with the CPU, publishes "taken" and enqueues private buffer -> device on its stream.  (A first version let both processes' copy
+//          engines work on the segment itself, registered as pinned memory in each; a three-process run then produced a wrong image once in
+//          a few dozen runs -- two GPU mappings of one set of pages is not something to build a checker on.)  A TEST TRANSPORT: it lets the slab drivers of fdw_slabs.cpp run as real processes whose streams know
 //          nothing of each other beyond message arrival -- which is what RCCL gives -- with all ranks on ONE GPU (tests/test_slabs_gpu.py,
 //          bench.py --backend shm).  Slow by design (two PCIe crossings per block); never chosen automatically.
 #include <dlfcn.h>
@@ -154,20 +157,27 @@ static_assert(sizeof(ShmBox) == 256, "box header");
 struct ShmSeg {
     char* base = nullptr;
     size_t bytes = 0;
-    bool pinned = false;
     std::vector<long> seq;                      // exchanges this rank has started
+    // process-private pinned staging (hipHostMalloc): what the copy engines of THIS process read and write
+    char* send_buf[2] = {nullptr, nullptr};     // [dir]
+    char* recv_buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [dir][exchange parity]
+    hipEvent_t recv_done[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // the upload out of recv_buf[dir][parity] has run
     ShmHeader* hdr() const { return reinterpret_cast<ShmHeader*>(base); }
     static size_t hdr_bytes() { return (sizeof(ShmHeader) + 4095) / 4096 * 4096; }
     ShmBox* box(int rank, int dir) const { return reinterpret_cast<ShmBox*>(base + hdr_bytes() + (size_t)(rank * 2 + dir) * (sizeof(ShmBox) + hdr()->cap_bytes)); }
     float* data(int rank, int dir) const { return reinterpret_cast<float*>(reinterpret_cast<char*>(box(rank, dir)) + sizeof(ShmBox)); }
 };
-struct ShmFlag {                                // argument of the host function that publishes a sequence number behind the copies on a stream
+struct ShmPost {                                // argument of the host function that runs behind the device -> private-buffer copies of one block
     std::atomic<long>* flag;
     long seq;
+    char* dst;                                  // the block's place in the segment
+    const char* src;                            // the private buffer the copies filled
+    size_t bytes;
 };
-void shm_publish(void* p)
+void shm_post(void* p)
 {
-    ShmFlag* f = static_cast<ShmFlag*>(p);
+    ShmPost* f = static_cast<ShmPost*>(p);
+    memcpy(f->dst, f->src, f->bytes);
     f->flag->store(f->seq, std::memory_order_release);
     delete f;
 }
@@ -301,9 +311,22 @@ extern "C" int fdw_comm_init_shm(const char* name, int rank, int world, int devi
         delete c;
         return fdw_fail(FDW_ECOMM, "rank %d: segment %s was not initialised by rank 0 for %d ranks x %zu bytes", rank, name, world, cap);
     }
-    // pinned: the staging copies become asynchronous DMA transfers (not required for correctness)
-    c->shm->pinned = hipHostRegister(m, bytes, hipHostRegisterPortable) == hipSuccess;
-    if (!c->shm->pinned) (void)hipGetLastError();
+    // private pinned staging: two send buffers, two pairs of receive buffers (a block is uploaded while the next one is copied out)
+    {
+        hipError_t e = hipSuccess;
+        for (int d = 0; d < 2 && e == hipSuccess; d++) {
+            e = hipHostMalloc((void**)&c->shm->send_buf[d], cap, hipHostMallocDefault);
+            for (int q = 0; q < 2 && e == hipSuccess; q++) {
+                e = hipHostMalloc((void**)&c->shm->recv_buf[d][q], cap, hipHostMallocDefault);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&c->shm->recv_done[d][q], hipEventDisableTiming);
+            }
+        }
+        if (e != hipSuccess) {
+            h->attached.fetch_add(1);           // the others must not wait for this rank for ever; they fail in their first exchange instead
+            fdw_comm_destroy(c);
+            return fdw_fail(FDW_ENOMEM, "comm_init_shm: pinned staging buffers (%zu bytes each): %s", cap, hipGetErrorString(e));
+        }
+    }
     h->attached.fetch_add(1);
     const bool all = shm_wait([&] { return h->attached.load() >= world; });
     if (rank == 0) (void)shm_unlink(name);
@@ -369,7 +392,13 @@ extern "C" void fdw_comm_destroy(fdw_comm* c)
     if (c->shm && c->shm->base) {
         (void)hipSetDevice(c->device);
         (void)hipDeviceSynchronize();           // host functions that publish into the segment have run
-        if (c->shm->pinned) (void)hipHostUnregister(c->shm->base);
+        for (int d = 0; d < 2; d++) {
+            if (c->shm->send_buf[d]) (void)hipHostFree(c->shm->send_buf[d]);
+            for (int q = 0; q < 2; q++) {
+                if (c->shm->recv_buf[d][q]) (void)hipHostFree(c->shm->recv_buf[d][q]);
+                if (c->shm->recv_done[d][q]) (void)hipEventDestroy(c->shm->recv_done[d][q]);
+            }
+        }
         munmap(c->shm->base, c->shm->bytes);
         c->shm->base = nullptr;
     }
@@ -415,18 +444,21 @@ int fdw_comm_exchange(fdw_comm* c, int nfields, float* const* fields, size_t sen
         if ((size_t)nfields * bytes > sg.hdr()->cap_bytes)
             return fdw_fail(FDW_ECOMM, "exchange: %d fields x %zu bytes exceed the segment's box capacity %zu (fdw_comm_init_shm box_bytes)", nfields, bytes, sg.hdr()->cap_bytes);
         const long seq = ++sg.seq[0];
-        // 1. my blocks into my boxes, behind everything queued on `stream`; the sequence number is published by a host function behind the copies
+        const int par = (int)(seq & 1);
+        // 1. my blocks: device -> private send buffer behind everything queued on `stream`; the host function behind the copies moves the block
+        //    into the segment and publishes the sequence number.  The send buffer and the box are free again once the previous block has been
+        //    posted (my own host function has run) and taken (the neighbour has copied it out).
         for (int d = 0; d < 2; d++) {
             if (!(d == 0 ? has_lo : has_hi)) continue;
             ShmBox* b = sg.box(c->rank, d);
-            if (!shm_wait([&] { return b->taken.load(std::memory_order_acquire) >= seq - 1; }))
+            if (!shm_wait([&] { return b->posted.load(std::memory_order_acquire) >= seq - 1 && b->taken.load(std::memory_order_acquire) >= seq - 1; }))
                 return fdw_fail(FDW_ECOMM, "exchange %ld: rank %d waited %lds for its previous halo rows to be taken", seq, c->rank, (long)kRendezvousTimeout.count());
             b->count = count; b->nfields = nfields;
             for (int f = 0; f < nfields; f++)
-                HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(sg.data(c->rank, d)) + (size_t)f * bytes, fields[f] + (d == 0 ? send_lo : send_hi), bytes, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipLaunchHostFunc(stream, shm_publish, new ShmFlag{&b->posted, seq}));
+                HIP_TRY(hipMemcpyAsync(sg.send_buf[d] + (size_t)f * bytes, fields[f] + (d == 0 ? send_lo : send_hi), bytes, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipLaunchHostFunc(stream, shm_post, new ShmPost{&b->posted, seq, reinterpret_cast<char*>(sg.data(c->rank, d)), sg.send_buf[d], (size_t)nfields * bytes}));
         }
-        // 2. the neighbours' blocks: wait (host) for their arrival in the segment, then segment -> ghost rows on my stream
+        // 2. the neighbours' blocks: wait (host) for their arrival in the segment, copy them out with the CPU, say so, upload from the private buffer
         for (int d = 0; d < 2; d++) {
             if (!(d == 0 ? has_lo : has_hi)) continue;
             const int nb = d == 0 ? c->rank - 1 : c->rank + 1;
@@ -436,9 +468,12 @@ int fdw_comm_exchange(fdw_comm* c, int nfields, float* const* fields, size_t sen
             if (b->posted.load() != seq || b->nfields != nfields || b->count != count)
                 return fdw_fail(FDW_ECOMM, "exchange %ld: rank %d and rank %d disagree (their message %ld: %d fields x %zu, mine %d x %zu)", seq, c->rank, nb,
                                 b->posted.load(), b->nfields, b->count, nfields, count);
+            HIP_TRY(hipEventSynchronize(sg.recv_done[d][par]));      // the upload of exchange seq - 2 out of this buffer has run
+            memcpy(sg.recv_buf[d][par], sg.data(nb, 1 - d), (size_t)nfields * bytes);
+            b->taken.store(seq, std::memory_order_release);
             for (int f = 0; f < nfields; f++)
-                HIP_TRY(hipMemcpyAsync(fields[f] + (d == 0 ? recv_lo : recv_hi), reinterpret_cast<char*>(sg.data(nb, 1 - d)) + (size_t)f * bytes, bytes, hipMemcpyHostToDevice, stream));
-            HIP_TRY(hipLaunchHostFunc(stream, shm_publish, new ShmFlag{&b->taken, seq}));
+                HIP_TRY(hipMemcpyAsync(fields[f] + (d == 0 ? recv_lo : recv_hi), sg.recv_buf[d][par] + (size_t)f * bytes, bytes, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipEventRecord(sg.recv_done[d][par], stream));
         }
         return FDW_OK;
     }

@@ -86,8 +86,16 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
     const int z0 = cell * 4;
     const unsigned voff = (unsigned)min(max(z0, 0), a.pitch - 4) * 4u;
     const bool own = (lane >= NS) && (lane <= 63 - NS) && (z0 >= 0) && (z0 < a.pitch);
+#if FDW_ABL_BITS & 8192          // timing experiment: no global stores
+    const unsigned soff = kLaneOff;
+#else
     const unsigned soff = (own && (BK == 1 || k >= NS - 2)) ? voff : kLaneOff;      // only the last two waves store (BK 1: all four levels are kept)
+#endif
+#if FDW_ABL_BITS & 16384         // timing experiment: no global loads
+    const unsigned loff = kLaneOff;
+#else
     const unsigned loff = first ? voff : kLaneOff;                        // only wave 0 loads
+#endif
     const unsigned row_bytes = (unsigned)a.pitch * 4u;
     const int rowmax = a.nxl - 1;
     const unsigned arr_bytes = (unsigned)a.nxl * row_bytes;               // < 2 GiB (checked by the host)
@@ -140,8 +148,13 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
         }
     };
     auto rowoff = [&](int row) -> unsigned { return LEAN ? (unsigned)row * row_bytes : (unsigned)min(max(row, 0), rowmax) * row_bytes; };
-    auto load_p = [&](int row) -> f4 { return f4_load_arr(rs_p, loff, rowoff(row), (FDW_NT & 4) != 0); };
-    auto load_pw = [&](__amdgpu_buffer_rsrc_t rs, int row) -> f4 { return f4_load_arr(rs, loff, rowoff(row), (FDW_NT & 1) != 0); };
+#if FDW_ABL_BITS & 4096          // timing experiment: every load of the march reads the chunk's first rows again (cache hits: the cost of the instructions without the memory behind them)
+    auto lrow = [&](int row) -> unsigned { return (unsigned)(max(xa, 0) + (row & 3)) * row_bytes; };
+#else
+    auto lrow = [&](int row) -> unsigned { return rowoff(row); };
+#endif
+    auto load_p = [&](int row) -> f4 { return f4_load_arr(rs_p, loff, lrow(row), (FDW_NT & 4) != 0); };
+    auto load_pw = [&](__amdgpu_buffer_rsrc_t rs, int row) -> f4 { return f4_load_arr(rs, loff, lrow(row), (FDW_NT & 1) != 0); };
 
     // rows: wave 0's centre row at march step m is s0 + m (what the global loads follow); this wave's is rk + m
     const int s0 = xa - (NS - 1) * H - D, b0 = s0 - H;

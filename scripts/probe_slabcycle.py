@@ -3,9 +3,10 @@
 slab driver, classic one-step cycles vs four-steps-per-pass cycles (development tool; projects the N-GPU rate an ideal link would give)."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))      # decomp_harness: the Python slab drivers are a test harness
 import torch
 import parallel_finite_difference_computation_amd as F
-from parallel_finite_difference_computation_amd.decomp import HipSlabStepper, SlabForward, SlabGeometry
+from decomp_harness import HipSlabStepper, SlabForward, SlabGeometry
 dev = torch.device("cuda:0")
 n = 8192
 for world in (2, 4, 8):

@@ -40,7 +40,7 @@ def main():
     wkey = head[head.index("--workload-key") + 1] if "--workload-key" in head else "forward"
     out = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     os.makedirs(out, exist_ok=True)
-    cmd_tail = ["--", "python3", os.path.join(ROOT, "bench.py")] + bench_args + ["--no-cpu-baseline", "--no-rest-line", "--no-fast-line"]
+    cmd_tail = ["--", "python3", os.path.join(ROOT, "bench.py")] + bench_args + ["--no-cpu-baseline", "--no-rest-line", "--no-fast-line", "--no-extra"]
     env = dict(os.environ, TMPDIR="/tmp")
 
     def run(name, args):

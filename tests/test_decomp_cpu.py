@@ -1,6 +1,7 @@
-"""CPU (gloo, world_size 2 and 3): the slab decomposition + deep-halo exchange logic of
-parallel_finite_difference_computation_amd.decomp, with the ORACLE as the compute kernel.
-Pass criterion: decomposed result is bit-identical to the single-domain oracle result."""
+"""CPU (gloo, world_size 2 and 3): the slab decomposition + deep-halo exchange scheme (row bookkeeping of
+parallel_finite_difference_computation_amd.decomp, cycles of tests/decomp_harness.py) with the ORACLE as the compute kernel.
+Pass criterion: decomposed result is bit-identical to the single-domain oracle result.  The product runs the same scheme inside
+libfdwave.so (csrc/fdw_slabs.cpp); its multi-process tests need a GPU (tests/test_slabs_gpu.py, process transport)."""
 import os
 import socket
 
@@ -12,7 +13,7 @@ import torch.multiprocessing as mp
 
 from conftest import assert_bit_equal, make_deck
 from oracle import oracle as O
-from parallel_finite_difference_computation_amd.decomp import SlabBack, SlabForward, SlabGeometry, slab_bounds
+from decomp_harness import SlabBack, SlabForward, SlabGeometry, slab_bounds
 
 
 class OracleSlabStepper:

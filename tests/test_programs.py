@@ -372,10 +372,10 @@ def test_reference_signature_compat_library():
                                         (2, ["--ksteps", "8", "--pipe", "on"]), (3, ["--ksteps", "4", "--pipe", "on", "--steps", "26"])],
                          ids=["2ranks-k4", "3ranks-auto-odd", "2ranks-pipeline-k8", "3ranks-pipeline-k4-leftover"])
 def test_multi_process_bench_rehearsal_on_one_gpu(ranks, opts, tmp_path):
-    """bench.py's N > 1 path end to end: torch.distributed.run, one process per slab, real HIP kernels, overlapped deep-halo
-    exchange (one-step kernels, and four steps per pass through the wave-pipeline kernel on four rotating buffers) -- with the
-    gloo backend so that all ranks can share this box's single GPU (RCCL refuses duplicate devices).
-    --check gathers the slabs and compares them bitwise with a single-domain run."""
+    """bench.py's N > 1 path end to end under an external launcher (torch.distributed.run): one process per slab, the C slab driver
+    (fdw_slabs_dev_forward) with its overlapped deep-halo exchange (one-step kernels, and four steps per pass through the wave-pipeline
+    kernel on four rotating buffers) -- over the library's process transport (--backend shm) so that all ranks can share this box's single
+    GPU (RCCL refuses duplicate devices).  The slabs are gathered and compared bitwise with a single-domain run."""
     import socket
     import sys
     s = socket.socket()
@@ -383,7 +383,7 @@ def test_multi_process_bench_rehearsal_on_one_gpu(ranks, opts, tmp_path):
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--size", "1024",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "shm", "--size", "1024",
            "--steps", "24", "--warmup", "6", "--check", "--no-cpu-baseline"] + opts
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=tmp_path)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -395,12 +395,12 @@ def test_multi_process_bench_rehearsal_on_one_gpu(ranks, opts, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload,backend", [("forward", "gloo"), ("forward", "shm"), ("rtm-slab", "shm")])
+@pytest.mark.parametrize("workload,backend", [("forward", "shm"), ("rtm-slab", "shm")])
 def test_bench_starts_its_own_ranks(workload, backend, tmp_path):
     """`python bench.py --gpus 2 ...` exactly as the driver calls it -- no launcher, no RANK / WORLD_SIZE in the environment: the parent starts
     the two ranks itself (before anything touches HIP), rank 0's JSON line is the LAST line on stdout, n_gpus = 2, exit status 0, and the
-    decomposed result equals the single-domain one bitwise.  gloo: the Python harness; shm: the C slab driver (fdw_slabs_*) over the
-    process transport of fdw_comm.cpp -- the code RCCL drives on a multi-GPU node, here with the two ranks sharing this box's GPU."""
+    decomposed result equals the single-domain one bitwise.  --backend shm: the C slab driver (fdw_slabs_*) over the process transport of
+    fdw_comm.cpp -- the code RCCL drives on a multi-GPU node, here with the two ranks sharing this box's GPU."""
     import json
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
@@ -442,12 +442,12 @@ def test_bench_multi_gpu_code_path_on_one_rank(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks,opts", [(1, []), (2, ["--backend", "gloo", "--ksteps", "4"]), (3, ["--backend", "gloo", "--ksteps", "3", "--steps", "11"])],
-                         ids=["1rank-c-driver", "2ranks-gloo-k4", "3ranks-gloo-k3-leftover"])
+@pytest.mark.parametrize("ranks,opts", [(1, []), (2, ["--backend", "shm", "--ksteps", "4"]), (3, ["--backend", "shm", "--ksteps", "3", "--steps", "11"])],
+                         ids=["1rank-c-driver", "2ranks-shm-k4", "3ranks-shm-k3-leftover"])
 def test_bench_rtm_slab_workload(ranks, opts, tmp_path):
-    """bench.py --workload rtm-slab: forward + backward + imaging of one shot under the slab decomposition.  One rank: the C driver
-    (fdw_slabs_*) on the whole grid; 2 and 3 ranks: real processes sharing this GPU over gloo through the Python harness
-    (decomp.SlabForward + SlabBack), with the gathered image compared bitwise with a single-domain run of the same shots."""
+    """bench.py --workload rtm-slab: forward + backward + imaging of one shot under the slab decomposition through the C driver (fdw_slabs_*).
+    One rank: the whole grid; 2 and 3 ranks: real processes sharing this GPU over the library's process transport, with the gathered image
+    compared bitwise with a single-domain run of the same shots."""
     import json
     import sys
     base = [os.path.join(ROOT, "bench.py"), "--workload", "rtm-slab", "--gpus", str(ranks), "--size", "1024", "--steps", "12", "--warmup", "4", "--no-cpu-baseline"] + opts
