@@ -2,7 +2,7 @@
 """What ONE rank of an N-way x-slab decomposition of the 8192^2 bench grid costs without its links (development tool): the C slab driver
 (fdw_slabs_dev_forward / fdw_slabs_dev_back) on the geometry of a middle rank with a communicator whose exchanges move nothing, so the
 figure is compute + host enqueue + stream choreography -- the ceiling ideal links would give.  Whole-job Gpoints/s = n^2 K / t.
-    python3 scripts/probe_slabs_c.py [n] [K]"""
+    python3 scripts/probe_slabs_c.py [n] [K]        (PROBE_NUMERICS=1: FAST numerics)"""
 import os
 import sys
 import time
@@ -21,7 +21,7 @@ NB = 64
 
 def run(world, ksteps, back):
     comm = F.Comm.stub(world // 2, world) if world > 1 else None
-    sl = F.Slabs(8, n, n, NB, NB, K, 0.75, 10.0, 10.0, 1e-3, comm=comm, compat=False, ksteps=ksteps)
+    sl = F.Slabs(8, n, n, NB, NB, K, 0.75, 10.0, 10.0, 1e-3, comm=comm, compat=False, ksteps=ksteps, numerics=int(os.environ.get("PROBE_NUMERICS", "0")))
     nfb, nrb = sl.back_buffers()
     fl = [1e-3 * torch.randn((sl.nxl, sl.pitch), device=dev) for _ in range(max(sl.nbuf, nfb) + nrb)]
     for f in fl:
