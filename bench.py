@@ -115,6 +115,8 @@ KERNEL_SOURCES = {      # the translation units behind each workload's dominant 
     "forward": ("fdw_stepn.hip", "fdw_step2.hip", "fdw_device.h", "fdw_kernels.h"),
     "forward-fast": ("fdw_stepn.hip", "fdw_step2.hip", "fdw_device.h", "fdw_kernels.h"),      # the same sources, NUM = 1 instantiations (--numerics fast)
     "model": ("fdw_stepn.hip", "fdw_device.h", "fdw_kernels.h"),
+    "model-fast": ("fdw_stepn.hip", "fdw_device.h", "fdw_kernels.h"),
+    "rtm-slab-fast": ("fdw_stepn.hip", "fdw_device.h", "fdw_kernels.h"),
     "rtm-slab": ("fdw_stepn.hip", "fdw_device.h", "fdw_kernels.h"),
     "stencil": ("fdw_step1.hip", "fdw_device.h", "fdw_kernels.h"),
 }
@@ -307,7 +309,8 @@ def run_model_workload(args):
     nt = K + W
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    ctx = F.FDWave(ORDER, n, n, NB, NB, nt, 0.01, DX, DX, DT, dialect=1)
+    NUM = 1 if args.numerics == "fast" else 0
+    ctx = F.FDWave(ORDER, n, n, NB, NB, nt, 0.01, DX, DX, DT, dialect=1, numerics=NUM)
     pitch = ctx.pitch
     v2 = torch.zeros((n, pitch), device=dev)
     v2[:, :n] = synthetic_velocity_rows(n, 0, n, dev)
@@ -353,21 +356,22 @@ def run_model_workload(args):
     finite = bool(torch.isfinite(newest).all().item()) and float(newest.abs().max().item()) > 0.0 and float(rec.abs().max().item()) > 0.0
     algo = ALGO_BYTES_PER_POINT * n * n * spl
     min_bytes = (ALGO_BYTES_PER_POINT if spl == 1 else MIN_BYTES_PER_POINT_PER_LAUNCH) * n * n
-    prof = offline_counters("model", n, spl)
+    prof = offline_counters("model-fast" if NUM else "model", n, spl)
     traffic = prof["hbm_bytes_per_launch"] if prof else None
     achieved = (traffic if traffic else min_bytes) / launch_s / 1e9
     out = {"metric": "Gpoints/s (stencil updates) + achieved HBM GB/s vs peak", "value": round(n * n * K / wall / 1e9, 3), "unit": "Gpoints/s",
            "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": round(wall * 1e3 / K, 6), "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded noise wavefield)",
            "config": {"workload": f"forward-modelling producer (mod_main of the CPU-serial sibling): fd_step + 7x7 Gaussian source + four-sided taper + "
-                                  f"trace recording fused in one launch per step, {n}x{n} fp32 extended grid, nxb=nzb={NB}, {K} steps",
+                                  f"trace recording fused in one launch per step, {n}x{n} fp32 extended grid, nxb=nzb={NB}, {K} steps"
+                                  + (", FAST numerics (weights carry their spacing, symmetric sums + fused multiply-adds)" if NUM else ""),
                       "grid": [n, n], "order": ORDER, "parallelism": "single"},
-           "result_finite_nonzero": finite,
+           "result_finite_nonzero": finite, "numerics": "fast" if NUM else "exact",
            "timing": {"windows": nwin, "window_steps": K, "statistic": "median window"},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "basis": "measured HBM-side bytes per launch" if traffic else "minimum bytes one launch must move",
                         "traffic_source": traffic_source_note(prof),
-                        "kernel": "fdw::fdw_stepn_kernel<4,4,true,3,2,true> (four time steps per launch)" if spl == 4 else "fdw::fdw_step_kernel<4,true,3,false,false,2,true>",
+                        "kernel": f"fdw::fdw_stepn_kernel<4,4,true,3,2,true,0,{NUM}> (four time steps per launch)" if spl == 4 else "fdw::fdw_step_kernel<4,true,3,false,false,2,true>",
                         "launch_us": round(launch_s * 1e6, 2), "steps_per_launch": spl, "min_bytes_per_launch": min_bytes,
                         "algorithmic_16B_model": {"bytes_per_launch": algo, "achieved": round(algo / launch_s / 1e9, 1),
                                                   "ratio_to_peak": round(algo / launch_s / 1e9 / HBM_PEAK_GBS, 4),
@@ -692,7 +696,7 @@ def run_rtm_slab_workload(args):
                "config": {"workload": f"RTM domain decomposition: one shot on a {n}x{n} fp32 grid in {world} x-slab(s): {K} forward steps + {K} backward iterations "
                                       f"with imaging, {me['g'].ksteps if world > 1 else 0} steps per halo exchange", "grid": [n, n], "order": ORDER,
                           "parallelism": f"slab{world}" if world > 1 else "single"},
-               "result_finite_nonzero": finite and nonzero,
+               "result_finite_nonzero": finite and nonzero, "numerics": "fast" if NUM else "exact",
                "halo_exchange": HALO_PATHS[comm.kind] if world > 1 else None,
                "decomposition_check": check,
                "rccl_ranks": comm.world if (comm is not None and comm.kind == "rccl") else None, "comm_ranks": comm.world if comm is not None else world,
@@ -707,7 +711,7 @@ def run_rtm_slab_workload(args):
                             "one_step_model": {"bytes": bytes_min, "achieved": round(bytes_min / wall / 1e9, 1),
                                                "note": "SURVEY.md 8(d)'s byte model of the one-step kernels (16 + 44 B/point per time index): a throughput figure, NOT a roofline fraction"}}}
         if back_launch_s:
-            prof = offline_counters("rtm-slab", n, 1)
+            prof = offline_counters("rtm-slab-fast" if NUM else "rtm-slab", n, 1)
             traffic = prof["hbm_bytes_per_launch"] if prof else None
             min_bytes = 44.0 * n * n                        # 6 fields in (F_k, F_k-1, r, r', v2, image) + 5 out per point and launch
             basis = traffic if traffic else min_bytes

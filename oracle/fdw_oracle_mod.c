@@ -92,6 +92,13 @@ void orc_mod_taper_apply(float *pp, int nx, int nz, int nxb, int nzb, const floa
     }
 }
 
+/* FAST numerics of the product for these dialects (include/fdwave.h fdw_params.numerics = 1; NOT the sibling's arithmetic, see the header of
+ * fdw_oracle.c): the weights carry their spacing (czf_k = c_k * dz2inv, cxf_k = c_k * dx2inv, c0 = czf_0 + cxf_0, all fp32) and the Laplacian is
+ * one chain of symmetric sums and fused multiply-adds, exactly the RTM dialect's FAST formula.  orc_mod_set_numerics(1) switches every loop
+ * of this file to it. */
+static int orc_mod_numerics = 0;
+void orc_mod_set_numerics(int numerics) { orc_mod_numerics = numerics; }
+
 /* FD:24-46 fd_step: ONE accumulator, z term then x term per tap, weights scaled per term; Laplacian only inside the
  * order/2 frame (zero elsewhere, FD:19); update on the whole grid */
 void orc_mod_fd_step(int order, const float *coefs, float dx2inv, float dz2inv, float dt2, const float *p, float *pp, const float *v2,
@@ -99,6 +106,24 @@ void orc_mod_fd_step(int order, const float *coefs, float dx2inv, float dz2inv, 
 {
     const int h = order / 2;
     float acm = 0;
+    if (orc_mod_numerics) {
+        float czf[65], cxf[65];
+        for (int io = 0; io <= order; io++) {
+            czf[io] = coefs[io] * dz2inv;
+            cxf[io] = coefs[io] * dx2inv;
+        }
+        const float c0 = czf[h] + cxf[h];
+        for (int ix = h; ix < nxe - h; ix++)
+            for (int iz = h; iz < nze - h; iz++) {
+                const float *q = p + (size_t)ix * nze + iz;
+                float acc = c0 * q[0];
+                for (int k = 1; k <= h; k++) {
+                    acc = fmaf(q[-k] + q[k], czf[h - k], acc);
+                    acc = fmaf(q[-(long)k * nze] + q[(long)k * nze], cxf[h - k], acc);
+                }
+                laplace[ix * nze + iz] = acc;
+            }
+    } else
     for (int ix = h; ix < nxe - h; ix++)
         for (int iz = h; iz < nze - h; iz++) {
             for (int io = 0; io <= order; io++) {

@@ -72,6 +72,7 @@ def _declare(L):
     L.orc_slab_back_iter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p] + [C.c_int] * 4 + [f32p, C.c_int, f32p]
     L.orc_stencil.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, f32p, f32p]
     L.orc_fused_steps.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, C.c_float, C.c_int]
+    L.orc_mod_set_numerics.argtypes = [C.c_int]
     L.orc_mod_taper_tables.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p]
     L.orc_mod_extendvel.argtypes = [C.c_int] * 4 + [f32p]
     L.orc_mod_ricker_wavelet.argtypes = [C.c_int, C.c_float, C.c_float, f32p]
@@ -220,11 +221,21 @@ def mod_ricker_wavelet(nt, dt, fpeak):
     return s
 
 
-def mod_shot(order, nx, nz, nxb, nzb, dx, dz, dt, fac, vel2, sx, sz, gz, srce):
+def mod_numerics(numerics):
+    """Switch the sibling-dialect loops of the oracle (mod_shot, mod_steps, rtm_stored_shot) to the product's FAST formula (1) or back to
+    the sibling's own arithmetic (0, what every parity pin refers to).  Module-level state: tests reset it."""
+    lib().orc_mod_set_numerics(int(numerics))
+
+
+def mod_shot(order, nx, nz, nxb, nzb, dx, dz, dt, fac, vel2, sx, sz, gz, srce, numerics=0):
     """mod_main's loop for one shot (mod_main.cpp:140-174): data[nx][nt]."""
     srce = np.ascontiguousarray(srce, np.float32)
     data = np.zeros((nx, srce.size), np.float32)
-    lib().orc_mod_shot(order, nx, nz, nxb, nzb, srce.size, dx, dz, dt, fac, np.ascontiguousarray(vel2, np.float32), sx, sz, gz, srce, data)
+    mod_numerics(numerics)
+    try:
+        lib().orc_mod_shot(order, nx, nz, nxb, nzb, srce.size, dx, dz, dt, fac, np.ascontiguousarray(vel2, np.float32), sx, sz, gz, srce, data)
+    finally:
+        mod_numerics(0)
     return data
 
 
@@ -263,13 +274,17 @@ def mod_taper_apply(field, nx, nz, nxb, nzb, fac, times=1):
     return out
 
 
-def rtm_stored_shot(order, nx, nz, nxb, nzb, dx, dz, dt, fac, vel2, sx, sz, gz, srce, dobs, shot=0):
+def rtm_stored_shot(order, nx, nz, nxb, nzb, dx, dz, dt, fac, vel2, sx, sz, gz, srce, dobs, shot=0, numerics=0):
     """rtm_main's loop for one shot (rtm_main.cpp:158-240): imloc[nx][nz]; dobs is the whole gather [ns][nx][nt]."""
     srce = np.ascontiguousarray(srce, np.float32)
     dobs = np.ascontiguousarray(dobs, np.float32).ravel()
     imloc = np.zeros((nx, nz), np.float32)
-    lib().orc_rtm_stored_shot(order, nx, nz, nxb, nzb, srce.size, dx, dz, dt, fac, np.ascontiguousarray(vel2, np.float32), sx, sz, gz, srce,
-                              dobs, dobs.size, shot, imloc)
+    mod_numerics(numerics)
+    try:
+        lib().orc_rtm_stored_shot(order, nx, nz, nxb, nzb, srce.size, dx, dz, dt, fac, np.ascontiguousarray(vel2, np.float32), sx, sz, gz, srce,
+                                  dobs, dobs.size, shot, imloc)
+    finally:
+        mod_numerics(0)
     return imloc
 
 

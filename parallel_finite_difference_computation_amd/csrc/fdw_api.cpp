@@ -63,6 +63,7 @@ struct fdw_ctx {
     int upd_x1 = 0, upd_z1 = 0, tz_x1 = 0, xt_lo = 0, xt_hi = 0;
     float dt2 = 0.f, dx2inv = 0.f, dz2inv = 0.f;
     float c0 = 0.f;                // FAST numerics: cz[h] + cx[h]
+    float fcx[FDW_MAX_ORDER + 1]{}, fcz[FDW_MAX_ORDER + 1]{};  // FAST numerics of dialects 1, 2: the weights with their spacing folded in (fp32 products)
     float cx[FDW_MAX_ORDER + 1]{}, cz[FDW_MAX_ORDER + 1]{};    // RTM weights (C libm variant unless coef_cxx); dialect MOD: unscaled
     float* d_rec = nullptr;     // dialect MOD: trace samples [nt][nx] of one shot
     size_t rec_cap = 0;
@@ -164,8 +165,6 @@ static int validate(const fdw_params* p, const fdw_slab* s)
     if (p->dialect != FDW_DIALECT_RTM && p->order > 2 * kMaxFastHalfOrder)
         return fail(FDW_EINVAL, "dialects 1 and 2 are built for orders 2..%d", 2 * kMaxFastHalfOrder);
     if (p->numerics != FDW_NUMERICS_EXACT && p->numerics != FDW_NUMERICS_FAST) return fail(FDW_EINVAL, "numerics=%d is unknown", p->numerics);
-    if (p->numerics == FDW_NUMERICS_FAST && p->dialect != FDW_DIALECT_RTM)
-        return fail(FDW_EINVAL, "numerics = FAST is defined for the RTM dialect (dialect %d keeps the sibling's arithmetic)", p->dialect);
     if (s->nxl <= p->order || s->x_off < 0 || s->x_off + s->nxl > p->nxe)
         return fail(FDW_EINVAL, "slab [%d,%d) does not fit the grid (nxe=%d) or is thinner than the stencil",
                     s->x_off, s->x_off + s->nxl, p->nxe);
@@ -258,7 +257,11 @@ extern "C" int fdw_create_slab(const fdw_params* prm, const fdw_slab* slab, int 
         c->cz[io] = mod ? w[io] : dz2inv * w[io];      // fd.c:33-34 scales inside every term
         c->cx[io] = mod ? w[io] : dx2inv * w[io];
     }
-    c->c0 = c->cz[c->h] + c->cx[c->h];      // FAST numerics: the centre point's weight (one fp32 add, part of that mode's definition)
+    for (int io = 0; io <= prm->order; io++) {      // FAST numerics of the sibling's dialects: c_k * d?2inv once, instead of inside every term
+        c->fcz[io] = mod ? w[io] * dz2inv : c->cz[io];
+        c->fcx[io] = mod ? w[io] * dx2inv : c->cx[io];
+    }
+    c->c0 = c->fcz[c->h] + c->fcx[c->h];    // FAST numerics: the centre point's weight (one fp32 add, part of that mode's definition)
     c->taper_x.assign(std::max(prm->nxb, 1), 1.0f);
     c->taper_z.assign(std::max(prm->nzb, 1), 1.0f);
     if (mod) {
@@ -460,9 +463,10 @@ static int step_impl(fdw_ctx* c, int mode, const float* d_p, float* d_pp, const 
     a.dt2 = c->dt2;
     a.c0 = c->c0;
     a.numerics = c->prm.numerics;
+    const bool fastw = c->prm.numerics == FDW_NUMERICS_FAST;      // (for the RTM dialect fcx / fcz are cx / cz)
     for (int io = 0; io <= 2 * kMaxFastHalfOrder; io++) {
-        a.cx[io] = io <= c->prm.order ? c->cx[io] : 0.0f;
-        a.cz[io] = io <= c->prm.order ? c->cz[io] : 0.0f;
+        a.cx[io] = io <= c->prm.order ? (fastw ? c->fcx[io] : c->cx[io]) : 0.0f;
+        a.cz[io] = io <= c->prm.order ? (fastw ? c->fcz[io] : c->cz[io]) : 0.0f;
     }
     if (a.r1 <= a.r0) return FDW_OK;
     if (c->nbatch > 1) {      // fdw_shot_batch: shot b = these pointers + b fields, its own gather, its own source row
@@ -601,7 +605,11 @@ static int step2_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
     a.dt2 = c->dt2;
     a.c0 = c->c0;
     a.numerics = c->prm.numerics;
-    for (int io = 0; io <= 2 * kMaxFastHalfOrder; io++) { a.cx[io] = c->cx[io]; a.cz[io] = c->cz[io]; }
+    for (int io = 0; io <= 2 * kMaxFastHalfOrder; io++) {
+        const bool fastw = c->prm.numerics == FDW_NUMERICS_FAST;
+        a.cx[io] = fastw ? c->fcx[io] : c->cx[io];
+        a.cz[io] = fastw ? c->fcz[io] : c->cz[io];
+    }
     const int ncells = c->pitch / 4;
     a.nstrip = (ncells + 59) / 60;
     a.nzblk = (a.nstrip + 3) / 4;
@@ -742,7 +750,11 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
     a.dt2 = c->dt2;
     a.c0 = c->c0;
     a.numerics = c->prm.numerics;
-    for (int io = 0; io <= 2 * kMaxFastHalfOrder; io++) { a.cx[io] = c->cx[io]; a.cz[io] = c->cz[io]; }
+    for (int io = 0; io <= 2 * kMaxFastHalfOrder; io++) {
+        const bool fastw = c->prm.numerics == FDW_NUMERICS_FAST;
+        a.cx[io] = fastw ? c->fcx[io] : c->cx[io];
+        a.cz[io] = fastw ? c->fcz[io] : c->cz[io];
+    }
     const int ncells = c->pitch / 4, own = 64 - 2 * kPipeSteps;
     a.nstrip = (ncells + own - 1) / own;
     a.nzblk = a.nstrip;

@@ -85,7 +85,6 @@ __device__ __forceinline__ void march(const StepArgs& a, const ShotView& sv, con
     const bool rec_here = DD && (a.rec != nullptr) && (a.rec_z >= zs) && (a.rec_z < zs + 256);
     const CoefPairs<H> cpk = coef_pairs<H>(a.cx, a.cz);
     const v2f c0p = v2f{a.c0, a.c0};                          // FAST numerics: weight of the centre point
-    static_assert(NUM == 0 || !DD, "FAST numerics are defined for the RTM dialect");
 
     // per-lane column masks and damping factors
     bool mlap[4], mupd[4], znc[4], znh[4], ihit[4];
@@ -222,6 +221,9 @@ __device__ __forceinline__ void march(const StepArgs& a, const ShotView& sv, con
                     for (int e = 0; e < 4; ++e)
                         if (z0 + e == a.rec_z) sv.rec[r - a.rec_x0] = c.v[e];      // interior point: its damping factors are 1.0f
                 }
+            }
+            if constexpr (DD && NUM == 0) {
+                // the sibling's own arithmetic: one accumulator, every term scaled by its spacing (laplacian_dd_pt)
                 float W[12];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { W[e] = lft.v[e]; W[4 + e] = c.v[e]; W[8 + e] = rgt.v[e]; }
@@ -236,7 +238,8 @@ __device__ __forceinline__ void march(const StepArgs& a, const ShotView& sv, con
                     res.v[e] = zedge ? (mupd[e] ? upd : ppt.v[e]) : upd;
                 }
             } else {
-                // packed pairs: same products and sums in the same order as laplacian_pt (see laplacian_pair)
+                // packed pairs: same products and sums in the same order as laplacian_pt (see laplacian_pair); FAST numerics (NUM 1, any
+                // dialect: the host hands over weights that carry their spacing): one chain of symmetric sums and fused multiply-adds
                 const ZPairs zp = zpairs(lft, c, rgt);
                 static_for<2>([&](auto PP) {
                     constexpr int P = decltype(PP)::value;
@@ -543,7 +546,7 @@ static hipError_t launch_fast_hp(const StepArgs& a, int mode, hipStream_t s)
 hipError_t launch_step_fast(const StepArgs& a, int h, int mode, int pf, hipStream_t s)
 {
     if (a.nper <= 0) return hipSuccess;
-    if (mode == FDW_MODE_MOD || mode == FDW_MODE_DD_FWD || mode == FDW_MODE_DD_RECV) return a.numerics ? hipErrorInvalidValue : launch_step_dd(a, h, mode, pf, s);
+    if (mode == FDW_MODE_MOD || mode == FDW_MODE_DD_FWD || mode == FDW_MODE_DD_RECV) return launch_step_dd(a, h, mode, pf, s);
     if (a.numerics) return launch_step_fastnum(a, h, mode, s);
     if (h == 4) {
         switch (pf) {
@@ -572,8 +575,30 @@ static hipError_t launch_dd_hp(const StepArgs& a, int mode, hipStream_t s)
     }
     return hipGetLastError();
 }
+// FAST numerics for these dialects (prefetch distance 2): the RTM dialect's symmetric-sum / fma chain on weights that carry their spacing
+template <int H>
+static hipError_t launch_dd_fast_h(const StepArgs& a, int mode, hipStream_t s)
+{
+    const dim3 grid(8 * a.nper, a.nbatch > 1 ? a.nbatch : 1), block(256);
+    switch (mode) {
+    case FDW_MODE_MOD:     hipLaunchKernelGGL((fdw_step_kernel<H, true, 3, false, false, 2, true, false, 1>), grid, block, 0, s, a); break;
+    case FDW_MODE_DD_FWD:  hipLaunchKernelGGL((fdw_step_kernel<H, true, 1, false, false, 2, true, false, 1>), grid, block, 0, s, a); break;
+    case FDW_MODE_DD_RECV: hipLaunchKernelGGL((fdw_step_kernel<H, true, 2, true, false, 2, true, false, 1>), grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
 hipError_t launch_step_dd(const StepArgs& a, int h, int mode, int pf, hipStream_t s)
 {
+    if (a.numerics) {
+        switch (h) {
+        case 1: return launch_dd_fast_h<1>(a, mode, s);
+        case 2: return launch_dd_fast_h<2>(a, mode, s);
+        case 3: return launch_dd_fast_h<3>(a, mode, s);
+        case 4: return launch_dd_fast_h<4>(a, mode, s);
+        default: return hipErrorInvalidValue;
+        }
+    }
     if (h == 4) {
         switch (pf) {
         case 1: return launch_dd_hp<4, 1>(a, mode, s);

@@ -69,7 +69,6 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
                                        f4 (*link)[2][2][ROWS][64], f4 (*fifo)[64], f4 (*imf)[64] = nullptr, f4 (*linkx)[2][2][ROWS][64] = nullptr)
 {
     static_assert(!LEAN || (!TAPER && INJ == 0), "the lean body has no damping, no injection (and records no trace)");
-    static_assert(NUM == 0 || !DD, "FAST numerics are defined for the RTM dialect");
     constexpr bool IMG = (BK == 2 || BK == 4);
     constexpr int D = (BK == 4) ? 1 : 0;                      // this role runs D march steps behind
     constexpr int DL = (BK >= 3) ? 1 : 0;                     // ... so both roles of the fused kernel loop one step longer
@@ -109,7 +108,7 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
 
     const bool wave_tap = TAPER && (cs * 4 < a.ztap);
     const bool xtap = wave_tap && ((xa - NS * H < a.xt_lo) || (xe + NS * H > a.xt_hi));
-    const CoefPairs<H> cpk = DD ? coef_pairs<H>(a.cz, a.cz) : coef_pairs<H>(a.cx, a.cz);      // DD: the unscaled weights (the spacings enter per term)
+    const CoefPairs<H> cpk = (DD && NUM == 0) ? coef_pairs<H>(a.cz, a.cz) : coef_pairs<H>(a.cx, a.cz);      // DD, exact: the unscaled weights (the spacings enter per term)
     const v2f ddinv = v2f{a.dz2inv, a.dx2inv};
     const v2f c0p = v2f{a.c0, a.c0};                                      // FAST numerics: weight of the centre point
     const int blob = (INJ == 3) ? 3 : 0;                                  // INJ 3: 7x7 Gaussian source of the CPU-serial sibling (ptsrc.c:49-55)
@@ -278,7 +277,8 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
             // the sibling's single-accumulator Laplacian, two cells per instruction (laplacian_dd_quad)
             const ZPairs zp = zpairs(lft, c1, rgt);
             v2f lapq[2];
-            laplacian_dd_quad<H>(zp, [&](auto IO) -> const f4& { return ring[(U + decltype(IO)::value) % R]; }, cpk, ddinv, lapq[0], lapq[1]);
+            if constexpr (NUM == 0) laplacian_dd_quad<H>(zp, [&](auto IO) -> const f4& { return ring[(U + decltype(IO)::value) % R]; }, cpk, ddinv, lapq[0], lapq[1]);
+            else lap_quad<1, H>(zp, [&](auto IO) -> const f4& { return ring[(U + decltype(IO)::value) % R]; }, cpk, c0p, lapq[0], lapq[1]);      // FAST: weights carry their spacing
             static_for<2>([&](auto PP) {
                 constexpr int P = decltype(PP)::value;
                 v2f lap2 = lapq[P];
@@ -499,10 +499,11 @@ hipError_t launch_stepn(const Step2Args& a, int h, int mode, hipStream_t s)
     if (a.nper <= 0) return hipSuccess;
     if (h != 4) return hipErrorInvalidValue;
     const dim3 grid(8 * a.nper), block(64 * kPipeSteps);
-    if (a.numerics) {      // FAST numerics (fdw_device.h): the same kernels with NUM = 1; RTM dialect only
+    if (a.numerics) {      // FAST numerics (fdw_device.h): the same kernels with NUM = 1
         switch (mode) {
         case FDW_MODE_FWD:   hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 1, FDW_PIPE_PF, false, 0, 1>), grid, block, 0, s, a); break;
         case FDW_MODE_PLAIN: hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, false, 0, FDW_PIPE_PF, false, 0, 1>), grid, block, 0, s, a); break;
+        case FDW_MODE_MOD:   hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 3, FDW_PIPE_PF, true, 0, 1>), grid, block, 0, s, a); break;
         case FDW_MODE_PLAIN_ALL: hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, false, 0, FDW_PIPE_PF, false, 1, 1>), grid, block, 0, s, a); break;
         case FDW_MODE_RECV:  hipLaunchKernelGGL((fdw_stepn_kernel<4, kPipeSteps, true, 2, FDW_PIPE_PF, false, 2, 1>), grid, block, 0, s, a); break;
         case FDW_MODE_BACK4: hipLaunchKernelGGL((fdw_back4_kernel<4, kPipeSteps, FDW_PIPE_PF, 1>), grid, dim3(128 * kPipeSteps), 0, s, a); break;

@@ -44,6 +44,7 @@ void orc_mod_shot(int order, int nx, int nz, int nxb, int nzb, int nt, float dx,
 void orc_rtm_stored_shot(int order, int nx, int nz, int nxb, int nzb, int nt, float dx, float dz, float dt, float fac, const float *v2, int sx, int sz, int gz,
                          const float *srce, const float *dobs_flat, size_t n_flat, int is, float *imloc);
 void orc_mod_ricker_wavelet(int nt, float dt, float peak, float *s);
+void orc_mod_set_numerics(int numerics);
 void orc_mod_extendvel(int nx, int nz, int nxb, int nzb, float *vel);
 void orc_image_laplacian(const float *img, int nx, int nz, float dx, float dz, float *out);
 void orc_image_compare(const float *f1, const float *f2, size_t n, float *diff, double *stats);
@@ -243,12 +244,14 @@ static void oracle_loops(void)
         float *img = (float *)calloc((size_t)nx * nz, sizeof(float)), *out = (float *)calloc((size_t)nx * nz, sizeof(float));
         if (!data || !img || !out) abort();
         for (int order = 2; order <= 8; order += 2) {
+            orc_mod_set_numerics((order / 2) & 1);      /* both numerics modes of these loops */
             orc_mod_shot(order, nx, nz, nxb, nzb, nt, 10.0f, 8.0f, 0.001f, 0.01f, v2, nxb + 3, nzb + 2, nzb + 1, srce, data);
             eat(data, (size_t)nx * nt);
             /* the gather as rtm_main indexes it: one sample past the last trace of the last shot reads as 0 (n_flat bounds it) */
             orc_rtm_stored_shot(order, nx, nz, nxb, nzb, nt, 10.0f, 8.0f, 0.001f, 0.01f, v2, nxb + 3, nzb + 2, nzb + 1, srce, data, (size_t)nx * nt, 0, img);
             eat(img, (size_t)nx * nz);
         }
+        orc_mod_set_numerics(0);
         orc_image_laplacian(img, nx, nz, 10.0f, 8.0f, out);
         eat(out, (size_t)nx * nz);
         double st[4];
