@@ -105,7 +105,7 @@ def main():
         lines.append("")
         if entry is None and d and bench_line is not None:       # the dominant kernel of the command
             entry = dict(workload=wkey, size=bench_line["config"]["grid"][0], steps_per_launch=bench_line.get("roofline", {}).get("steps_per_launch", 1),
-                         kernel=kname, source_hash=kernel_source_hash(wkey), source=f"profiles/r02_pmc_{tag}.txt", sq_source=f"profiles/r02_pmc_{tag}.txt", **d)
+                         kernel=kname, source_hash=kernel_source_hash(wkey), source=f"profiles/r03_pmc_{tag}.txt", sq_source=f"profiles/r03_pmc_{tag}.txt", **d)
             if st:
                 entry["kernel_trace_avg_us"] = round(float(st["AverageNs"]) / 1e3, 2)
     if bench_line is not None:
