@@ -533,7 +533,7 @@ int fdw_comm_exchange(fdw_comm* c, int nfields, float* const* fields, size_t sen
 extern "C" int fdw_comm_allreduce(fdw_comm* c, double* value, int op_max)
 {
     if (!c || !value) return fdw_fail(FDW_EINVAL, "allreduce: NULL argument");
-    if (c->world == 1 || c->stub) return FDW_OK;
+    if (c->stub || (c->world == 1 && !c->nccl)) return FDW_OK;      // (a one-rank RCCL communicator still goes through ncclAllReduce: the only way a one-GPU box can exercise that call)
     if (c->nccl) {
         // RCCL reduces device memory: one double per rank through a device word, ncclSum / ncclMax on ncclFloat64 (any value survives)
         HIP_TRY(hipSetDevice(c->device));

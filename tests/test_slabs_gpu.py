@@ -137,6 +137,7 @@ def test_rccl_communicator_single_rank():
     assert (c.rank, c.world, c.device) == (0, 1, 0)
     c.selftest()
     assert c.allreduce(3.5) == 3.5 and c.allreduce(-2.0, "max") == -2.0
+    assert c.allreduce(1.0 + 2.0 ** -40) == 1.0 + 2.0 ** -40 and c.allreduce(-1e300, "max") == -1e300      # ncclAllReduce on ncclFloat64 (a float would lose both)
     d, srce, d_obs, im0 = _case(120, 140, 16, 9, True)
     want, _, _ = _single(d, srce, d_obs, im0)
     s = F.Slabs(d["order"], 120, 140, 16, 16, 9, d["fac"], d["dx"], d["dz"], d["dt"], comm=c, compat=True)
