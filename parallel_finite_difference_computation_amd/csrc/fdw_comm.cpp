@@ -72,7 +72,7 @@ Rccl* rccl()
     std::call_once(once, [] {
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names)
-            if ((r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+            if ((r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;      // (a copy already in the process -- PyTorch's -- is found by its SONAME and reused)
         if (!r.so) {
             snprintf(r.why, sizeof r.why, "librccl.so.1 cannot be loaded: %s", dlerror());
             return;

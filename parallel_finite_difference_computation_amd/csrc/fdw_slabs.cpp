@@ -263,8 +263,9 @@ extern "C" int fdw_slabs_dev_forward(fdw_slabs* s, float* const* buf, const floa
         const bool more = done + kk < nsteps;
         float* pair[2] = {buf[*ip], buf[*ipp]};                 // by role: older, newer
         FDW_TRY(s->pre(2, pair));
-        if (s->pipe && kk == s->ksteps) {
-            // ---- passes of four steps over the four rotating buffers ----
+        if (s->pipe && kk % kPipe == 0) {
+            // ---- passes of four steps over the four rotating buffers (a leftover cycle of 4, 8, ... steps too: the ghost band is wide enough for
+            //      any cycle up to ksteps; only leftovers that are no multiple of four go step by step) ----
             const int passes = kk / kPipe;
             const bool split_last = s->overlap && s->world > 1 && more && (s->o1 - s->o0) >= 2 * G + 16;
             for (int j = 1; j <= passes; j++) {

@@ -82,6 +82,11 @@ int main(int argc, char **argv)
     prm.order = order; prm.nxe = nxe; prm.nze = nze; prm.nxb = nxb; prm.nzb = nzb; prm.nt = nt;
     prm.dx = dx; prm.dz = dz; prm.dt = dt; prm.fac = fac;
     prm.dialect = FDW_DIALECT_RTM_STORED;
+    {   /* our extension, absent = the reference's arithmetic: numerics=1 (or FDW_NUMERICS=1) selects FAST numerics (include/fdwave.h) */
+        int numerics = fdw_deck_int(deck, "numerics");
+        if (getenv("FDW_NUMERICS")) numerics = atoi(getenv("FDW_NUMERICS"));
+        prm.numerics = numerics == 1 ? FDW_NUMERICS_FAST : FDW_NUMERICS_EXACT;
+    }
     fdw_ctx *ctx = NULL;
     if (fdw_create(&prm, 0, &ctx) != FDW_OK) {              /* fd_init + taper_init, M:134-135 */
         fprintf(stderr, "fdw_create: %s\n", fdw_last_error());

@@ -51,6 +51,11 @@ int main(int argc, char **argv)
     prm.dx = dx; prm.dz = dz; prm.dt = 0.0f; prm.fac = 1.0f;
     prm.compat = 0;
     prm.coef_cxx = 1;                   /* S:184-216 is compiled as C++ */
+    {   /* our extension, absent = the reference's arithmetic: numerics=1 (or FDW_NUMERICS=1) selects FAST numerics (include/fdwave.h) */
+        int numerics = fdw_deck_int(deck, "numerics");
+        if (getenv("FDW_NUMERICS")) numerics = atoi(getenv("FDW_NUMERICS"));
+        prm.numerics = numerics == 1 ? FDW_NUMERICS_FAST : FDW_NUMERICS_EXACT;
+    }
     fdw_ctx *ctx = NULL;
     if (fdw_create(&prm, 0, &ctx) != FDW_OK) {
         fprintf(stderr, "fdw_create: %s\n", fdw_last_error());

@@ -45,7 +45,8 @@ def read_deck(path):
         f = lambda k: float(L.fdw_deck_float(h, k.encode()))
         d = dict(tmpdir=s("tmpdir"), vpfile=s("vpfile"), datfile=s("datfile"), vel_ext_file=s("vel_ext_file"),
                  nz=i("nz"), nx=i("nx"), nt=i("nt"), ns=i("ns"), sz=i("sz"), fsx=i("fsx"), ds=i("ds"), gz=i("gz"),
-                 order=i("order"), nzb=i("nzb"), nxb=i("nxb"), dz=f("dz"), dx=f("dx"), dt=f("dt"), fpeak=f("fpeak"), fac=f("fac"))
+                 order=i("order"), nzb=i("nzb"), nxb=i("nxb"), dz=f("dz"), dx=f("dx"), dt=f("dt"), fpeak=f("fpeak"), fac=f("fac"),
+                 numerics=i("numerics"))
     finally:
         L.fdw_deck_free(h)
     for key, default in (("ns", 1), ("sz", 0), ("fsx", 0), ("ds", 1), ("gz", 0), ("order", 8), ("nzb", 40), ("nxb", 40)):
@@ -53,6 +54,9 @@ def read_deck(path):
             d[key] = default
     if d["fac"] == -1.0:
         d["fac"] = np.float32(0.7).item()
+    if "FDW_NUMERICS" in os.environ:
+        d["numerics"] = int(os.environ["FDW_NUMERICS"])
+    d["numerics"] = 1 if d["numerics"] == 1 else 0      # our extension (absent = the reference's arithmetic): numerics=1 selects FAST numerics (fdwave.h)
     return d
 
 
@@ -78,6 +82,7 @@ def run(deck_path, out=sys.stdout):
     d = read_deck(deck_path)
     nx, nz, nt, ns, nxb, nzb = d["nx"], d["nz"], d["nt"], d["ns"], d["nxb"], d["nzb"]
     nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+    numerics = d["numerics"]
     say = (lambda *a: print(*a, file=out, flush=True)) if rank == 0 else (lambda *a: None)
     say(f"## vp = {d['vpfile']}, d_obs = {d['datfile']}, vel_ext_file = {d['vel_ext_file']}, vel_ext_flag = {int(d['vel_ext_file'] is not None)} ")
     say(f"## nz = {nz}, nx = {nx}, nt = {nt} ")
@@ -101,7 +106,7 @@ def run(deck_path, out=sys.stdout):
 
     def one_shot(s, v2):
         if not hasattr(local_ctx, "ctx"):
-            local_ctx.ctx = api.FDWave(d["order"], nxe, nze, nxb, nzb, nt, d["fac"], d["dx"], d["dz"], d["dt"], compat=True, device=local)
+            local_ctx.ctx = api.FDWave(d["order"], nxe, nze, nxb, nzb, nt, d["fac"], d["dx"], d["dz"], d["dt"], compat=True, device=local, numerics=numerics)
             if dev_border:
                 local_ctx.ctx.model_resident(vp)
         ctx = local_ctx.ctx
@@ -115,7 +120,7 @@ def run(deck_path, out=sys.stdout):
     # a batch need consecutive places in the rand() stream and equally spaced sources, which consecutive shots have, fd-code.cu:405-407)
     batched = False
     if (dev_border or vel_ext is not None) and "FDW_NO_SHOT_BATCH" not in os.environ:
-        ctx = api.FDWave(d["order"], nxe, nze, nxb, nzb, nt, d["fac"], d["dx"], d["dz"], d["dt"], compat=True, device=local)
+        ctx = api.FDWave(d["order"], nxe, nze, nxb, nzb, nt, d["fac"], d["dx"], d["dz"], d["dt"], compat=True, device=local, numerics=numerics)
         B = ctx.shot_batch_max()
         if B <= 1:
             ctx.close()        # the probing context is not needed: the per-thread contexts below do the work

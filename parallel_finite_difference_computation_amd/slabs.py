@@ -13,6 +13,19 @@ from .api import FDWave, _f32
 ID_BYTES = 128
 
 
+def _one_rccl():
+    """Before the first RCCL entry point of libfdwave.so in a Python process: load PyTorch if it is installed.  The library opens librccl.so.1
+    with dlopen, and the dynamic linker hands it the copy PyTorch already holds (same SONAME) -- but not the other way round: libtorch_hip asks
+    for "librccl.so" by file name next to itself, so a process that opened the system RCCL first and imports torch later ends up with TWO RCCL
+    libraries whose global state collides (seen as "double free or corruption" at interpreter exit once ncclAllReduce had run in one of them).
+    C programs (rtm_code slabs=N) never load PyTorch and are not concerned."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
+
 class Comm:
     """One rank of a communicator.  Build with Comm.rccl(...) or Comm.local(world)."""
 
@@ -22,12 +35,14 @@ class Comm:
     @staticmethod
     def unique_id():
         """ncclGetUniqueId: call on rank 0 and hand the bytes to every rank."""
+        _one_rccl()
         buf = C.create_string_buffer(ID_BYTES)
         check(lib().fdw_comm_get_unique_id(buf))
         return buf.raw
 
     @classmethod
     def rccl(cls, unique_id, rank, world, device):
+        _one_rccl()
         h = C.c_void_p()
         check(lib().fdw_comm_init_rank(C.create_string_buffer(bytes(unique_id), ID_BYTES), rank, world, device, C.byref(h)))
         return cls(h)

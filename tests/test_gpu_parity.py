@@ -1131,7 +1131,8 @@ def test_unequal_spacings_through_every_rtm_kernel(case, spacing, monkeypatch):
             assert_bit_equal(got[b], orc.back(v2_all[b], bP, bPP, gathers[b], d["gz"]), f"batched shot {b}")
 
 
-def test_random_decks_property():
+@pytest.mark.parametrize("numerics", [0, 1], ids=["exact", "fast"])
+def test_random_decks_property(numerics):
     """Property test (hypothesis): for randomly drawn small decks -- any even order up to 10, ragged extents, borders from 0 up, truncated or
     full launch extents, the source anywhere the reference can time-step it, every forward kernel -- fdw_shot's fields and image equal the
     oracle's bit for bit."""
@@ -1161,7 +1162,9 @@ def test_random_decks_property():
 
     seen, spacings = [], set()
 
-    @settings(max_examples=int(os.environ.get("FDW_PROPERTY_EXAMPLES", "150")), deadline=None, suppress_health_check=list(HealthCheck),
+    nex = int(os.environ.get("FDW_PROPERTY_EXAMPLES", "150"))      # numerics = 1: the same decks in FAST numerics against the oracle's FAST restatement
+
+    @settings(max_examples=nex, deadline=None, suppress_health_check=list(HealthCheck),
               derandomize="FDW_PROPERTY_RANDOM" not in os.environ, database=None)
     @given(decks())
     def check(c):
@@ -1172,7 +1175,8 @@ def test_random_decks_property():
         nx, nz = c["nxe"] - 2 * c["nxb"], c["nze"] - 2 * c["nzb"]
         srce = (O.ricker_wavelet(c["nt"], d["dt"], 30.0) + 0.5).astype(np.float32)
         d_obs = np.random.default_rng(c["seed"]).standard_normal((nx, c["nt"])).astype(np.float32)
-        ctx, orc = mk(d), mko(d)
+        ctx = mk(d, numerics=numerics)
+        orc = O.Oracle(d["order"], d["nxe"], d["nze"], d["nxb"], d["nzb"], d["nt"], d["fac"], d["dx"], d["dz"], d["dt"], compat=d.get("compat", True), numerics=numerics)
         ctx.set_tuning(two_step=c["mode"])
         img, P, PP = ctx.shot(d["v2"], c["sx"], c["sz"], c["gz"], srce, d_obs, want_fields=True)
         oP, oPP = orc.forward(d["v2"], c["sx"], c["sz"], srce)

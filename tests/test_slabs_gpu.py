@@ -117,6 +117,36 @@ def test_c_slab_driver_as_real_processes(world, ksteps, shape, compat, pipe, tmp
     assert np.abs(want - im0).max() > 0
 
 
+@pytest.mark.parametrize("world,ksteps,nt", [(2, 8, 20), (3, 16, 40), (2, 12, 30)], ids=["k8-leftover4", "k16-leftover8", "k12-leftover6-stepwise"])
+def test_c_slab_driver_leftover_cycles_through_the_pipeline(world, ksteps, nt, monkeypatch):
+    """A run whose length is no multiple of the steps per exchange: the leftover cycle goes through four-step passes too when it is a multiple
+    of four (the driver's `bench.py --gpus N --steps 20` is 16 + 4), step by step otherwise (30 = 12 + 12 + 6: one pass + two single steps...
+    a leftover of 6 goes step by step).  Image, P and PP equal fdw_shot bit for bit."""
+    nxe, nze = 64 * world + 2 * 4 * ksteps * world + 211, 1500
+    d, srce, d_obs, im0 = _case(nxe, nze, 40, nt, True)
+    want, P, PP = _single(d, srce, d_obs, im0)
+    monkeypatch.setenv("FDW_SLAB_PIPE", "1")
+    comms = F.Comm.local(world)
+
+    def rank(r):
+        s = F.Slabs(d["order"], nxe, nze, d["nxb"], d["nzb"], nt, d["fac"], d["dx"], d["dz"], d["dt"], comm=comms[r], compat=True, ksteps=ksteps)
+        assert s.nbuf == 4 and s.ksteps == ksteps
+        out = s.shot(d["v2"], d["sx"], d["sz"], d["gz"], srce, d_obs, imloc=im0, want_fields=True)
+        geo = (s.own0, s.own1, s.owned_interior_rows())
+        s.close()
+        return out, geo
+
+    img, gP, gPP = np.array(im0), np.zeros_like(P), np.zeros_like(PP)
+    for (im, p, pp), (o0, o1, (a, b)) in F.run_ranks(rank, world):
+        img[a:b] = im[a:b]
+        gP[o0:o1], gPP[o0:o1] = p[o0:o1], pp[o0:o1]
+    for c in comms:
+        c.close()
+    assert_bit_equal(gPP, PP, "PP gathered from the ranks")
+    assert_bit_equal(gP, P, "P gathered from the ranks")
+    assert_bit_equal(img, want, "image gathered from the ranks")
+
+
 def test_c_slab_driver_single_rank_equals_fdw_shot():
     d, srce, d_obs, im0 = _case(210, 300, 24, 21, True, dx=25.0, dz=8.0)
     want, P, PP = _single(d, srce, d_obs, im0)
