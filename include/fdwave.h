@@ -134,8 +134,10 @@ int fdw_shot(fdw_ctx *ctx, const float *v2, int sx, int sz, int gz, const float 
  * reference damps those rows with taperx every step although nothing ever rewrites them (R:94-117 with the grids of R:185-195); the kernels
  * here damp on load instead of in place (csrc/fdw_device.h, "lazy taper") and cannot reproduce that for rows they never store.  Every call
  * site of the reference satisfies it (fields start at zero, R:496-497, R:511-514, and snapshots come from such runs).  The host-array entry
- * points check it and return FDW_EINVAL; the fdw_dev_* ones cannot (the data is on the device) -- a caller that violates it gets values
- * in those few rows of the strip that differ from the reference's.  A source row in those rows is refused (FDW_EINVAL) by every path.
+ * points check it and return FDW_EINVAL; the fdw_dev_* ones do not look at the data (it is on the device, and they are asynchronous) -- a
+ * caller that violates it gets values in those few rows of the strip that differ from the reference's.  fdw_dev_check_field(ctx, d_field,
+ * stream) runs the same check ON the device for such a caller (synchronises `stream`; FDW_EINVAL with the count of offending cells).
+ * A source row in those rows is refused (FDW_EINVAL) by every path.
  *
  * fdw_dev_step    one fused time step on rows [r0,r1) of the slab:
  *                   mode 0 FWD   taper + Laplacian + leap-frog + point source  (R:264-267)
@@ -208,6 +210,7 @@ int fdw_dev_step4(fdw_ctx *ctx, const float *d_p, const float *d_pp, const float
 int fdw_dev_steps2(fdw_ctx *ctx, float *const *d_buf, const float *d_v2, const float *d_srce, int sx, int sz, int it0, int nsteps,
                    int first_pp_twice, int *ip, int *ipp, void *stream);
 int fdw_dev_taper_finalize(fdw_ctx *ctx, float *d_f, void *stream);
+int fdw_dev_check_field(fdw_ctx *ctx, const float *d_f, void *stream);
 int fdw_dev_laplacian(fdw_ctx *ctx, const float *d_p, float *d_lap, void *stream);
 
 /* ---- forward-modelling producer -------------------------------------------------------

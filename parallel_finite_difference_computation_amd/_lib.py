@@ -56,6 +56,7 @@ SIGNATURES = [
     ("fdw_dev_step4", C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp] + [C.c_int] * 7 + [vp]),
     ("fdw_dev_steps2", C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), vp]),
     ("fdw_dev_taper_finalize", C.c_int, [vp, vp, vp]),
+    ("fdw_dev_check_field", C.c_int, [vp, vp, vp]),
     ("fdw_model_shot", C.c_int, [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, f32p]),
     ("fdw_image_laplacian", C.c_int, [C.c_int, f32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p]),
     ("fdw_image_compare", C.c_int, [C.c_int, f32p, f32p, C.c_size_t, vp, C.POINTER(C.c_double), C.c_int]),

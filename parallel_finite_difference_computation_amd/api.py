@@ -269,6 +269,11 @@ class FDWave:
         check(lib().fdw_rtm_stored_shot(self._h, _f32(vel2, (self.nxe, self.nze)), sx, sz, gz, srce, srce.size, dobs, dobs.size, shot, imloc))
         return imloc
 
+    def dev_check_field(self, d_f, stream=None):
+        """The precondition of the lazy damping checked on a DEVICE array (compat extents: the damped strip must be zero on the rows the
+        reference never time-steps; fdwave.h).  Raises FdwError if it is violated; synchronises the stream."""
+        check(lib().fdw_dev_check_field(self._h, d_f, stream))
+
     def set_store_budget(self, nbytes):
         """Bytes the stored source fields of rtm_stored_shot may occupy (0: no limit of our own).  Below nt + 1 fields the shot checkpoints and
         recomputes (fdwave.h); the image stays bit-identical."""

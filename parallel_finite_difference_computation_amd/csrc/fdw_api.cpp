@@ -977,6 +977,32 @@ static int check_static_taper_rows(const fdw_ctx* c, const float* f, const char*
     return FDW_OK;
 }
 
+// the same precondition for a DEVICE array (fdw_border.hip; declared here rather than in fdw_kernels.h, whose text is part of the kernel-source hash of bench.py)
+namespace fdw {
+hipError_t launch_static_strip_check(const float* f, int pitch, int row0, int nrows, int ztap, unsigned* flag, hipStream_t s);
+}
+extern "C" int fdw_dev_check_field(fdw_ctx* c, const float* d_f, void* stream)
+{
+    if (!c || !d_f) return fail(FDW_EINVAL, "ctx or field is NULL");
+    const int row0 = std::max(c->xlim - c->slab.x_off, 0);              // local rows the reference never time-steps
+    if (row0 >= c->nxl || c->ztap <= 0) return FDW_OK;                  // nothing to check on this grid / slab
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = pick_stream(c, stream);
+    unsigned* d_flag = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_flag, sizeof(unsigned)));
+    unsigned bad = 0;
+    hipError_t e = hipMemsetAsync(d_flag, 0, sizeof(unsigned), s);
+    if (e == hipSuccess) e = launch_static_strip_check(d_f, c->pitch, row0, c->nxl - row0, c->ztap, d_flag, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_flag);
+    if (e != hipSuccess) return fail(FDW_EHIP, "fdw_dev_check_field: %s", hipGetErrorString(e));
+    if (bad)
+        return fail(FDW_EINVAL, "%u cells of the damped strip (columns < %d) are non-zero on rows the reference never time-steps (global rows >= %d): "
+                                "in compat mode they must be zero (R:185-195; include/fdwave.h, PRECONDITION)", bad, c->ztap, c->xlim);
+    return FDW_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-array entry points
 // ------------------------------------------------------------------------------------------------

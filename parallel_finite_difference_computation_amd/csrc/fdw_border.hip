@@ -161,4 +161,22 @@ hipError_t launch_extendvel(const BorderArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- the precondition of the lazy damping, checked on the device (include/fdwave.h, "PRECONDITION") -------------------------------------
+// With the reference's truncated launch extents the rows >= xlim are never time-stepped, yet the reference damps them inside the top strip
+// every step; the kernels damp on load and cannot reproduce that, so those cells must be zero (as at every call site of the reference).
+// The host-array entry points check it on the host; this kernel lets a caller of the fdw_dev_* entry points check a DEVICE array:
+// *flag += number of non-zero cells among rows [row0, nxl) x columns [0, ztap).
+__global__ __launch_bounds__(256) void fdw_static_strip_check_kernel(const float* __restrict__ f, int pitch, int row0, int ztap, unsigned* __restrict__ flag)
+{
+    const int z = blockIdx.x * 256 + threadIdx.x, r = row0 + blockIdx.y;
+    if (z >= ztap) return;
+    if (f[(size_t)r * pitch + z] != 0.0f) atomicAdd(flag, 1u);
+}
+hipError_t launch_static_strip_check(const float* f, int pitch, int row0, int nrows, int ztap, unsigned* flag, hipStream_t s)
+{
+    if (nrows <= 0 || ztap <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fdw_static_strip_check_kernel, dim3((ztap + 255) / 256, nrows), dim3(256), 0, s, f, pitch, row0, ztap, flag);
+    return hipGetLastError();
+}
+
 }  // namespace fdw

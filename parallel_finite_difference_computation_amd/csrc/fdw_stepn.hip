@@ -81,12 +81,6 @@ __device__ __forceinline__ void marchn(const Step2Args& a, const int lane, const
     static_assert(ROWS == 1 || (ROWS == 2 && R % 2 == 0), "one or two rows per barrier");
     static_assert(BK < 3 || ROWS == 1, "the fused backward kernel assumes one row per barrier");
     const bool first = WK == 1 ? true : (WK == 2 ? false : (k == 0));      // WK 1 / 2: the body compiled for wave 0 / for the other waves
-#ifdef FDW_PIPE_PRIO0            // experiment: issue priority of the wave that streams from global memory (the others stay at 0)
-    if (first) __builtin_amdgcn_s_setprio(FDW_PIPE_PRIO0);
-#endif
-#ifdef FDW_PIPE_PRIOST           // experiment: issue priority of the waves that store to global memory
-    if (k >= NS - 2) __builtin_amdgcn_s_setprio(FDW_PIPE_PRIOST);
-#endif
     const int cell = cs + lane;
     const int z0 = cell * 4;
     const unsigned voff = (unsigned)min(max(z0, 0), a.pitch - 4) * 4u;

@@ -639,6 +639,25 @@ def test_committed_bench_lines_keep_the_contract():
         assert os.path.exists(os.path.join(root, "..", e["source"])), e["source"]
 
 
+def test_committed_counter_profiles_belong_to_the_current_kernel_sources():
+    """profiles/traffic.json (what bench.py's roofline.traffic quotes) was taken on exactly the kernel sources in the tree: every entry carries
+    the hash of the translation units behind its workload, and bench.py drops an entry whose hash is stale -- this test makes a kernel edit
+    that forgets to re-profile visible here instead of silently turning `traffic` into null on the driver's run."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_for_hash", os.path.join(ROOT, "bench.py"))
+    # bench.py imports torch at module level; the hash helper itself needs nothing of it
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    ns = {"os": os, "ROOT": ROOT}
+    start, end = src.index("KERNEL_SOURCES = {"), src.index("def offline_counters(")
+    exec(src[start:end], ns)
+    entries = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert {e["workload"] for e in entries} >= {"forward", "forward-fast", "rtm-slab", "model", "stencil"}
+    for e in entries:
+        assert e["source_hash"] == ns["kernel_source_hash"](e["workload"]), f"profiles/traffic.json: the {e['workload']} {e['size']} entry ({e['source']}) is stale: re-profile (scripts/profile_all.sh)"
+        assert os.path.exists(os.path.join(ROOT, e["source"])), e["source"]
+
+
 def test_built_library_has_no_store_followed_by_a_write_of_its_data():
     """scripts/lint_store_hazard.py on the built libfdwave.so: no 96 / 128-bit vector store (buffer with or without a register soffset, global,
     flat, scratch) is followed within two wait states -- along straight-line code or across a branch -- by a VALU write of its data
