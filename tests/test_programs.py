@@ -614,10 +614,14 @@ def test_committed_bench_lines_keep_the_contract():
     import glob
     import json
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
-    files = sorted(glob.glob(os.path.join(root, "r02_bench_*.json")))
-    assert len(files) >= 6
+    files = sorted(glob.glob(os.path.join(root, "r02_bench_*.json")) + glob.glob(os.path.join(root, "r03_bench_*.json")))
+    assert len(files) >= 16
     for f in files:
         d = json.loads(open(f).read().strip().splitlines()[-1])
+        if "ranks_shm_rehearsal" in f:      # functional rehearsals of the N > 1 path on one GPU: the line's shape, not its value
+            assert d["n_gpus"] in (2, 4) and d["rccl_ranks"] is None and d["comm_ranks"] == d["n_gpus"] and "bitwise equal" in d["decomposition_check"]
+            assert 0.0 <= d["exposed_comm_fraction"] <= 1.0 and d["launched_by"].startswith("bench.py itself")
+            continue
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
             assert key in d, f"{os.path.basename(f)}: {key} missing"
         assert d["unit"] == "Gpoints/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["n_gpus"] == 1
@@ -633,6 +637,11 @@ def test_committed_bench_lines_keep_the_contract():
         if "cpu_baseline" in d:
             for key in ("value", "unit", "cores", "kind", "sample"):
                 assert key in d["cpu_baseline"], f"{os.path.basename(f)}: cpu_baseline.{key} missing"
+        if os.path.basename(f) in ("r03_bench_8192_steps20.json", "r03_bench_8192_steps1000.json"):      # the driver's line: headline EXACT, the rest beside it
+            assert d["numerics"] == "exact" and d["roofline"]["traffic"] and d["cpu_baseline"]["cores"] >= 1
+            fl, ex = d["fast_numerics"], d["extra"]["baseline_config_2"]
+            assert fl["value"] > d["value"] and fl["roofline"]["traffic"] and 0.0 < fl["roofline"]["frac"] <= 1.0
+            assert ex["grid"] == [4096, 4096] and ex["steps"] == 1000 and ex["value"] > 0
     entries = json.load(open(os.path.join(root, "traffic.json")))
     assert {e["workload"] for e in entries} >= {"forward", "stencil", "rtm-slab", "model"}
     for e in entries:
