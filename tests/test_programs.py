@@ -173,6 +173,23 @@ def test_rtm_code_program_vs_oracle_pipeline(tmp_path, with_vel_ext):
     assert np.allclose(last, img, rtol=1e-5, atol=1e-5 * np.abs(img).max())
 
 
+def test_bench_self_launch_without_a_gpu_fails_fast_and_clean(tmp_path):
+    """The launcher of `python bench.py --gpus N` on a box WITHOUT a GPU (this container): it starts its N ranks before touching HIP itself, every
+    rank finds no device and exits non-zero, the launcher reports that status without a JSON line and without waiting for a timeout.  (On a GPU
+    box the -m gpu tests run the same launcher to a result.)"""
+    import sys
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by test_bench_starts_its_own_ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "shm", "--size", "1024", "--steps", "8", "--warmup", "4",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=tmp_path, env=env)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "no GPU visible" in r.stderr and time.time() - t0 < 120
+
+
 def test_rtm_code_refuses_more_slabs_than_gpus(tmp_path):
     """slabs=N over RCCL needs N GPUs, one rank each: with fewer visible (none in the authoring container, one on a GPU box) the program must
     say so and exit at once -- before it creates a communicator or a thread, because a rank that never arrives would leave the others
