@@ -227,6 +227,114 @@ HALO_PATHS = {"rccl": "RCCL ncclSend/ncclRecv groups issued by libfdwave.so on t
               "local": "device copies between ranks-as-threads inside libfdwave.so"}
 
 
+def rccl_rehearsal_main(uid_hex):
+    """`python bench.py --rccl-rehearsal <unique id, hex>` (RANK / WORLD_SIZE / LOCAL_RANK in the environment): a SHORT slab run over RCCL in a
+    process of its own -- communicator, the self-addressed message, 32 forward steps of a 4096-row grid through the C slab driver (the halo
+    exchange of the measurement itself), one all-reduce.  Prints RCCL-REHEARSAL-OK.  The ranks of the measurement start one each
+    (rccl_or_fallback) so that a collective library that hangs or crashes on this machine costs the rehearsal, not the measurement."""
+    rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FDW_BENCH_REHEARSAL_HANG") == "1":       # tests: a rehearsal that never comes back
+        time.sleep(3600)
+    if os.environ.get("FDW_BENCH_SHARE_GPU") == "1":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    comm = F.Comm.rccl(bytes.fromhex(uid_hex), rank, world, local_rank)
+    comm.selftest()
+    n, nt = 4096, 32
+    sl = F.Slabs(ORDER, n, n, NB, NB, nt, FAC, DX, DX, DT, comm=comm, compat=False, device=local_rank)
+    fld = [torch.zeros((sl.nxl, sl.pitch), device=dev) for _ in range(sl.nbuf)]
+    fld[0][:, :n] = 1e-3 * torch.randn((sl.nxl, n), device=dev)
+    v2 = torch.zeros((sl.nxl, sl.pitch), device=dev)
+    v2[:, :n] = synthetic_velocity_rows(n, sl.x_off, sl.nxl, dev)
+    srce = torch.from_numpy(F.ricker_wavelet(nt, DT, FPEAK)).to(dev)
+    torch.cuda.synchronize()
+    ip, _ = sl.dev_forward([f_.data_ptr() for f_ in fld], v2.data_ptr(), srce.data_ptr(), n // 2, n // 2, 0, nt)
+    sl.synchronize()
+    torch.cuda.synchronize()
+    ok = bool(torch.isfinite(fld[ip]).all().item())
+    total = comm.allreduce(1.0 if ok else 0.0)
+    sl.close()
+    comm.close()
+    if total != float(world):
+        sys.exit(f"rccl rehearsal: {total} of {world} ranks finished with finite fields")
+    print("RCCL-REHEARSAL-OK", flush=True)
+
+
+def rccl_rehearsal(rank, world, local_rank, dist):
+    """None if a rehearsal of the RCCL halo exchange (rccl_rehearsal_main, one child process per rank, bounded in time) went through on every
+    rank, else the reason it did not.  FDW_BENCH_NO_REHEARSAL=1 skips it."""
+    import signal
+    import subprocess
+    if os.environ.get("FDW_BENCH_NO_REHEARSAL") == "1":
+        return None
+    limit = float(os.environ.get("FDW_BENCH_REHEARSAL_TIMEOUT", "240"))
+    why, uid = None, [None]
+    if rank == 0:
+        try:
+            uid = [F.Comm.unique_id().hex()]
+        except F.FdwError as e:
+            why = f"rank 0 could not create the RCCL unique id: {e}"
+    dist.broadcast_object_list(uid, src=0)
+    if uid[0] is not None:
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rccl-rehearsal", uid[0]], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                 text=True, start_new_session=True)
+        try:
+            out, _ = child.communicate(timeout=limit)
+            if child.returncode != 0 or "RCCL-REHEARSAL-OK" not in out:
+                why = f"the rehearsal of rank {rank} ended with status {child.returncode}: {out.strip()[-300:]}"
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)             # exactly the process started above (its own session)
+            except OSError:
+                pass
+            child.wait()
+            why = f"the rehearsal of rank {rank} did not finish within {limit:.0f} s"
+    reasons = [None] * world
+    dist.all_gather_object(reasons, why)
+    bad = [r for r in reasons if r]
+    return bad[0] if bad else None
+
+
+def rccl_or_fallback(args, rank, world, local_rank, n, dist):
+    """(communicator, reason) of a run on `world` > 1 ranks: RCCL inside libfdwave.so (ncclGetUniqueId on rank 0, the bytes to every rank through
+    the control-plane group, ncclCommInitRank, one message to the own rank as a check) after its rehearsal in child processes went through.
+    Should RCCL not be usable from the C library on this machine -- an error, a crash or a hang of the rehearsal -- every rank falls back,
+    together, to the library's process transport (halo blocks staged through shared memory: slow, flagged in the line; reason = why) rather
+    than lose the measurement altogether."""
+    if args.backend == "shm":
+        return shm_communicator(rank, world, local_rank, n), None
+    why = rccl_rehearsal(rank, world, local_rank, dist)
+    comm = None
+    if why is None:
+        err, uid = None, [None]
+        if rank == 0:
+            try:
+                uid = [F.Comm.unique_id()]
+            except F.FdwError as e:
+                err = e
+        dist.broadcast_object_list(uid, src=0)
+        if uid[0] is not None:
+            try:
+                comm = F.Comm.rccl(uid[0], rank, world, local_rank)
+                comm.selftest()
+            except F.FdwError as e:
+                err = e
+        else:
+            err = err or RuntimeError("rank 0 could not create the RCCL unique id")
+        reasons = [None] * world
+        dist.all_gather_object(reasons, None if err is None else str(err))
+        bad = [r for r in reasons if r]
+        why = bad[0] if bad else None
+    if why is None:
+        return comm, None
+    print(f"[bench] rank {rank}: RCCL inside libfdwave.so is not usable here ({why}); falling back to the library's process transport (shared-memory staging)",
+          file=sys.stderr, flush=True)
+    if comm is not None:
+        comm.close()
+    return shm_communicator(rank, world, local_rank, n), why
+
+
 def synthetic_velocity_rows(n, row0, rows, device):
     """v(ix,iz) = 1500 + 2500*iz/(nze-1) with a 3 % lateral sinusoid (m/s)."""
     z = torch.arange(n, device=device, dtype=torch.float32)[None, :]
@@ -530,7 +638,7 @@ def run_rtm_slab_workload(args):
         if world == 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    if args.backend != "nccl":
+    if args.backend != "nccl" or os.environ.get("FDW_BENCH_SHARE_GPU") == "1":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -587,13 +695,9 @@ def run_rtm_slab_workload(args):
         st["sl"].synchronize()
         torch.cuda.synchronize()
 
-    comm = None
-    if c_driver and world > 1 and args.backend == "shm":
-        comm = shm_communicator(rank, world, local_rank, n)
-    elif c_driver and world > 1:
-        uid = [F.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = F.Comm.rccl(uid[0], rank, world, local_rank)
+    comm = rccl_fallback = None
+    if world > 1:
+        comm, rccl_fallback = rccl_or_fallback(args, rank, world, local_rank, n, dist)
     me = make_rank(comm, world, rank)
     torch.cuda.synchronize()
 
@@ -697,7 +801,7 @@ def run_rtm_slab_workload(args):
                                       f"with imaging, {me['g'].ksteps if world > 1 else 0} steps per halo exchange", "grid": [n, n], "order": ORDER,
                           "parallelism": f"slab{world}" if world > 1 else "single"},
                "result_finite_nonzero": finite and nonzero, "numerics": "fast" if NUM else "exact",
-               "halo_exchange": HALO_PATHS[comm.kind] if world > 1 else None,
+               "halo_exchange": (HALO_PATHS[comm.kind] + (f" -- FALLBACK: RCCL was not usable from libfdwave.so ({rccl_fallback})" if rccl_fallback else "")) if world > 1 else None,
                "decomposition_check": check,
                "rccl_ranks": comm.world if (comm is not None and comm.kind == "rccl") else None, "comm_ranks": comm.world if comm is not None else world,
                "exposed_comm_fraction": exposed["value"] if exposed else None, "exposed_comm": exposed,
@@ -790,7 +894,13 @@ def main():
     ap.add_argument("--no-fast-line", action="store_true", help="forward workload, N = 1: skip the extra measurement in FAST numerics")
     ap.add_argument("--init", choices=["noise", "rest"], default="noise",
                     help="initial wavefield: seeded noise (default; every cache line carries real data) or at rest (zeros + source)")
+    ap.add_argument("--rccl-rehearsal", default=None, metavar="UNIQUE_ID_HEX",
+                    help="internal: what each rank of an N > 1 run starts as a child process before it opens RCCL itself (rccl_rehearsal_main)")
     args = ap.parse_args()
+    if args.rccl_rehearsal is not None:
+        if not torch.cuda.is_available():
+            sys.exit("bench: no GPU visible (the product has no CPU path)")
+        return rccl_rehearsal_main(args.rccl_rehearsal)
     MAX_WINDOWS[0] = max(1, args.max_windows)
     if os.environ.get("FDW_BENCH_POISON") == "1":
         poison_free_memory()
@@ -814,8 +924,8 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (the product has no CPU path)")
-    if args.backend != "nccl":
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)     # rehearsal: several ranks may share one GPU
+    if args.backend != "nccl" or os.environ.get("FDW_BENCH_SHARE_GPU") == "1":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)     # rehearsal: several ranks may share one GPU (FDW_BENCH_SHARE_GPU: tests of the RCCL fallback)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -841,36 +951,15 @@ def main():
         # and one message to the own rank as a check.  Should librccl not be usable from the C library on this machine, every rank falls back
         # -- together -- to the library's process transport (halo blocks staged through shared memory: slow, flagged in the line) rather than
         # lose the measurement altogether.
-        err = None
-        uid = [None]
-        if args.backend == "shm" and world > 1:
-            comm = shm_communicator(rank, world, local_rank, n)
-        else:
-            if rank == 0:
-                try:
-                    uid = [F.Comm.unique_id()]
-                except F.FdwError as e:
-                    err = e
-            if world > 1:
-                dist.broadcast_object_list(uid, src=0)
-            if uid[0] is not None:
-                try:
-                    comm = F.Comm.rccl(uid[0], rank, world, local_rank)
-                    comm.selftest()
-                except F.FdwError as e:
-                    err = e
-            else:
-                err = err or RuntimeError("rank 0 could not create the RCCL unique id")
-            bad = torch.tensor([1.0 if err is not None else 0.0])
-            if world > 1:
-                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-            if bad.item() > 0:
-                print(f"[bench] rank {rank}: RCCL inside libfdwave.so is not usable here ({err}); falling back to the library's process transport (shared-memory staging)",
-                      file=sys.stderr, flush=True)
-                if comm is not None:
-                    comm.close()
-                rccl_fallback = str(err) if err is not None else "another rank could not open RCCL"
-                comm = shm_communicator(rank, world, local_rank, n) if world > 1 else None
+        if world > 1:
+            comm, rccl_fallback = rccl_or_fallback(args, rank, world, local_rank, n, dist)
+        else:                                   # FDW_FORCE_SLAB_DRIVER=c: the slab driver on one rank, over a one-rank RCCL communicator if there is one
+            try:
+                comm = F.Comm.rccl(F.Comm.unique_id(), 0, 1, local_rank)
+                comm.selftest()
+            except F.FdwError as e:
+                print(f"[bench] RCCL inside libfdwave.so is not usable here ({e}); one slab without a communicator", file=sys.stderr, flush=True)
+                comm = None
         if args.pipe != "auto":
             os.environ["FDW_SLAB_PIPE"] = "1" if args.pipe == "on" else "0"
         if args.no_overlap:

@@ -436,6 +436,39 @@ def test_bench_starts_its_own_ranks(workload, backend, tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_rccl_rehearsal_on_one_rank(tmp_path):
+    """What every rank of an N > 1 run starts before it opens RCCL itself (bench.py --rccl-rehearsal): communicator, self-addressed message,
+    32 steps through the C slab driver, all-reduce -- here as a world of one rank, the most this box's single GPU lets RCCL do."""
+    import sys
+    import parallel_finite_difference_computation_amd as F
+    uid = F.Comm.unique_id().hex()
+    env = dict({k: v for k, v in os.environ.items() if k not in ("MASTER_ADDR", "MASTER_PORT")}, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rccl-rehearsal", uid], capture_output=True, text=True, timeout=600, cwd=tmp_path, env=env)
+    assert r.returncode == 0 and "RCCL-REHEARSAL-OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["refused", "hangs"])
+def test_bench_falls_back_when_the_rccl_rehearsal_fails(how, tmp_path):
+    """`bench.py --gpus 2` with the default back end where RCCL cannot work: both ranks on this box's one GPU (RCCL refuses duplicate devices:
+    the rehearsal children fail), and a rehearsal that never returns (killed at its time limit).  Either way the ranks fall back together to
+    the process transport, the line says so, and the decomposed result still equals the single-domain one."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["FDW_BENCH_SHARE_GPU"] = "1"
+    if how == "hangs":
+        env.update(FDW_BENCH_REHEARSAL_HANG="1", FDW_BENCH_REHEARSAL_TIMEOUT="8")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "1024", "--steps", "24", "--warmup", "6", "--check",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=tmp_path, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] is None and "FALLBACK" in out["halo_exchange"] and "bitwise equal" in out["decomposition_check"]
+    if how == "hangs":
+        assert "did not finish within 8 s" in out["halo_exchange"]
+
+
+@pytest.mark.gpu
 def test_bench_self_launch_reports_a_failing_rank(tmp_path):
     """A rank that dies must not leave the launcher waiting: non-zero exit, no JSON line."""
     import sys
