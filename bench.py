@@ -282,7 +282,7 @@ def rccl_rehearsal(rank, world, local_rank, dist):
         try:
             out, _ = child.communicate(timeout=limit)
             if child.returncode != 0 or "RCCL-REHEARSAL-OK" not in out:
-                why = f"the rehearsal of rank {rank} ended with status {child.returncode}: {out.strip()[-300:]}"
+                why = f"the rehearsal of rank {rank} ended with status {child.returncode}: {(out.strip().splitlines() or [''])[-1][-300:]}"
         except subprocess.TimeoutExpired:
             try:
                 os.killpg(child.pid, signal.SIGKILL)             # exactly the process started above (its own session)
