@@ -1242,7 +1242,9 @@ def main():
             launch_s = dev_ms * 1e-3 / launches
             algo = ALGO_BYTES_PER_POINT * pts_per_launch * steps_per_launch      # 16 B/point/step x steps in one launch
             min_bytes = (ALGO_BYTES_PER_POINT if steps_per_launch == 1 else MIN_BYTES_PER_POINT_PER_LAUNCH) * pts_per_launch
-            prof = offline_counters("forward", n, steps_per_launch)
+            prof = offline_counters("forward-fast" if NUM else "forward", n, steps_per_launch)
+            if NUM:
+                kname = kname.replace("> (", ",0,1> (FAST numerics; ") if "> (" in kname else kname + " with NUM = 1 (FAST numerics)"
             traffic = prof["hbm_bytes_per_launch"] if prof else None
             basis_bytes = traffic if traffic else min_bytes
             achieved = basis_bytes / launch_s / 1e9
@@ -1257,9 +1259,11 @@ def main():
                                "algorithmic_16B_model": {"bytes_per_launch": algo, "achieved": round(algo / launch_s / 1e9, 1),
                                                          "ratio_to_peak": round(algo / launch_s / 1e9 / HBM_PEAK_GBS, 4), "note": model_note}}
             if prof and prof.get("valu_busy") is not None:
-                out["roofline"]["issue"] = {"bound": "valu-issue", "valu_busy": prof["valu_busy"], "salu_per_valu": prof.get("salu_per_valu"),
+                out["roofline"]["issue"] = {"bound": "memory-path" if NUM else "valu-issue", "valu_busy": prof["valu_busy"], "salu_per_valu": prof.get("salu_per_valu"),
                                             "source": prof.get("sq_source"),
-                                            "note": "SQ counters: the kernel saturates the vector issue slots well below the HBM line; see DESIGN.md section 4"}
+                                            "note": ("SQ counters: with half the Laplacian's instructions the vector units idle; the kernel is bound by the memory path (ablations in "
+                                                     "profiles/r03_fast_ablations.txt, DESIGN.md section 3e)") if NUM else
+                                                    "SQ counters: the kernel saturates the vector issue slots well below the HBM line; see DESIGN.md section 4"}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(n)
                 sib = reference_sibling_cpu(min(n, 2048), 100)      # the reference's own CPU code for the same stencil (its two-pass fd_step), beside our port

@@ -7,6 +7,7 @@ python bench.py 2>>$o/bench_err.log | j > $o/${r}_bench_8192_steps1000.json
 python bench.py --size 4096 --no-cpu-baseline 2>>$o/bench_err.log | j > $o/${r}_bench_4096.json
 python bench.py --size 16384 --steps 400 --no-cpu-baseline 2>>$o/bench_err.log | j > $o/${r}_bench_16384.json
 python bench.py --numerics fast --no-cpu-baseline 2>>$o/bench_err.log | j > $o/${r}_bench_8192_fast.json
+python bench.py --size 16384 --steps 400 --numerics fast --no-cpu-baseline 2>>$o/bench_err.log | j > $o/${r}_bench_16384_fast.json
 python bench.py --workload rtm-slab --steps 202 --warmup 10 2>>$o/bench_err.log | j > $o/${r}_bench_rtm_slab_8192.json
 python bench.py --workload rtm-slab --steps 202 --warmup 10 --numerics fast --no-cpu-baseline 2>>$o/bench_err.log | j > $o/${r}_bench_rtm_slab_8192_fast.json
 python bench.py --workload model --steps 200 --warmup 20 2>>$o/bench_err.log | j > $o/${r}_bench_model_8192.json

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: the profile set of a round (kernel trace + one counter group per pass each; scripts/profile_bench.py), in two or three calls:
-#   scripts/profile_all.sh a | b | c        outputs under gpurun_out/prof_<tag>/ ; scripts/collect_profiles.py copies what is judged into profiles/
+#   scripts/profile_all.sh a | b | c | d        outputs under gpurun_out/prof_<tag>/ ; scripts/collect_profiles.py copies what is judged into profiles/
 set -x
 P="python3 scripts/profile_bench.py"
 case "$1" in
@@ -14,4 +14,5 @@ c) $P model8192 --workload-key model -- --workload model --steps 200 --warmup 20
    $P model8192fast --workload-key model-fast -- --workload model --numerics fast --steps 200 --warmup 20
    $P stencil8192 --workload-key stencil -- --workload stencil --steps 200 --warmup 20
    $P fwd4096fast --workload-key forward-fast -- --numerics fast --size 4096 --steps 1000 --warmup 50 ;;
+d) $P fwd16384fast --workload-key forward-fast -- --numerics fast --size 16384 --steps 100 --warmup 12 ;;
 esac

@@ -684,6 +684,8 @@ def test_committed_bench_lines_keep_the_contract():
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
         if r["traffic"] is not None:
             assert "profiles/" in r.get("traffic_source", ""), os.path.basename(f)
+            if os.path.basename(f).startswith("r03_"):      # a FAST line quotes the counter profile of the FAST kernels, an EXACT line that of the EXACT ones
+                assert ("fast.txt" in r["traffic_source"]) == (d.get("numerics") == "fast"), f"{os.path.basename(f)}: {d.get('numerics')} line quotes {r['traffic_source']}"
         if "cpu_baseline" in d:
             for key in ("value", "unit", "cores", "kind", "sample"):
                 assert key in d["cpu_baseline"], f"{os.path.basename(f)}: cpu_baseline.{key} missing"
