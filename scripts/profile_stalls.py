@@ -33,6 +33,7 @@ PASSES = [
     "TCC_HIT TCC_MISS TCC_REQ TCC_TAG_STALL",
     "TCC_EA0_RDREQ_DRAM_CREDIT_STALL TCC_EA0_WRREQ_DRAM_CREDIT_STALL TCC_SRC_FIFO_FULL TCC_LATENCY_FIFO_FULL",
     "GRBM_GUI_ACTIVE GRBM_COUNT",
+    "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_IFETCH_LEVEL",
 ]
 
 
@@ -46,7 +47,10 @@ def main():
     tail = ["--", "python3", os.path.join(ROOT, "bench.py")] + bench_args + ["--no-cpu-baseline", "--no-rest-line", "--no-fast-line", "--no-extra"]
     env = dict(os.environ, TMPDIR="/tmp")
     skipped = []
+    only = [int(x) for x in os.environ["FDW_STALL_PASSES"].split(",")] if os.environ.get("FDW_STALL_PASSES") else None      # e.g. FDW_STALL_PASSES=0,13
     for i, ctrs in enumerate(PASSES):
+        if only is not None and i not in only:
+            continue
         log = open(os.path.join(out, f"pmc{i}.log"), "w")
         # (a counter group the hardware cannot collect together makes rocprofv3 abort and then sit in its signal handler: bounded, and ended by PID)
         child = subprocess.Popen(["rocprofv3", "--pmc"] + ctrs.split() + ["-d", os.path.join(out, f"pmc{i}"), "--output-format", "csv"] + tail,
@@ -93,13 +97,15 @@ def main():
         ratio("time a read stays at the memory interface (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ)", "TCC_EA0_RDREQ_LEVEL", "TCC_EA0_RDREQ", unit=" cycles")
         ratio("time a write stays at the memory interface", "TCC_EA0_WRREQ_LEVEL", "TCC_EA0_WRREQ", unit=" cycles")
         ratio("L2 hit rate", "TCC_HIT", "TCC_REQ")
+        ratio("instruction-cache miss rate (SQC_ICACHE_MISSES / SQC_ICACHE_REQ)", "SQC_ICACHE_MISSES", "SQC_ICACHE_REQ")
+        ratio("average time an instruction fetch is in flight (SQ_IFETCH_LEVEL / SQ_IFETCH)", "SQ_IFETCH_LEVEL", "SQ_IFETCH", unit=" cycles")
         ratio("L2 cycles stalled on the write interface per L2 cycle", "TCC_EA0_WRREQ_STALL", "TCC_CYCLE")
         ratio("texture-address cycles stalled by the cache per busy cycle", "TA_ADDR_STALLED_BY_TC_CYCLES", "TA_BUSY")
         ratio("texture-data cycles stalled by the cache per busy cycle", "TA_DATA_STALLED_BY_TC_CYCLES", "TA_BUSY")
         lines.append("")
     if skipped:
         lines.append("passes the profiler refused: " + "; ".join(skipped))
-    for ln in open(os.path.join(out, "pmc0.log")):
+    for ln in (open(os.path.join(out, "pmc0.log")) if os.path.exists(os.path.join(out, "pmc0.log")) else ()):
         if ln.startswith("{") and '"metric"' in ln:
             lines.append("bench line of the first pass: " + ln.strip()[:400] + " ...")
     open(os.path.join(out, "summary.txt"), "w").write("\n".join(lines) + "\n")
