@@ -240,7 +240,8 @@ def test_random_slab_decompositions_property(monkeypatch):
     assert {p for _, p in seen} == {True, False} and len({w for w, _ in seen}) >= 3
 
 
-def test_full_size_shot_is_reproducible_and_writes_nothing_it_did_not_compute():
+@pytest.mark.parametrize("numerics", [0, 1], ids=["exact", "fast"])
+def test_full_size_shot_is_reproducible_and_writes_nothing_it_did_not_compute(numerics):
     """The bench's single-rank shot (8192^2, C slab driver: forward, hand-over, fused backward passes) repeated from the same start: fields
     and image identical run to run, and the receiver field EXACTLY zero beyond the reach of the receiver line (4 columns per iteration).
     This is the check that exposed the gfx950 store hazard (csrc/fdw_device.h, f4_store_arr): a buffer_store_dwordx4 with an SGPR soffset
@@ -249,7 +250,7 @@ def test_full_size_shot_is_reproducible_and_writes_nothing_it_did_not_compute():
     import torch
     n, nb, K = 8192, 64, 14                                  # 2 single iterations + 3 fused passes
     dev = torch.device("cuda:0")
-    sl = F.Slabs(8, n, n, nb, nb, K, 0.75, 10.0, 10.0, 1e-3, comm=None, compat=False)
+    sl = F.Slabs(8, n, n, nb, nb, K, 0.75, 10.0, 10.0, 1e-3, comm=None, compat=False, numerics=numerics)      # (the FAST kernels are instantiations of their own)
     nfb, nrb = sl.back_buffers()
     assert (nfb, nrb) == (6, 4), "the fused backward pipeline is expected to run at this size"
     nsrc = max(sl.nbuf, nfb)
