@@ -17,7 +17,7 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 dev = torch.device("cuda:0")
 nx, gz, sx, sz = n - 2 * NB, NB + 3, n // 2, NB + 2
-sl = F.Slabs(ORDER, n, n, NB, NB, K, FAC, DX, DX, DT, comm=None, compat=False)
+sl = F.Slabs(ORDER, n, n, NB, NB, K, FAC, DX, DX, DT, comm=None, compat=False, numerics=int(os.environ.get("STRESS_NUMERICS", "0")))      # STRESS_NUMERICS=1: the FAST instantiations
 nfb, nrb = sl.back_buffers()
 nsrc = max(sl.nbuf, nfb)
 srce = torch.from_numpy(F.ricker_wavelet(K, DT, FPEAK)).to(dev)
