@@ -180,9 +180,9 @@ def test_fast_six_shot_image_of_new_mod_within_tolerance():
     assert worst > 0.0 and np.abs(stack[0]).max() > 0
 
 
-@pytest.mark.parametrize("n,nsteps", [(4096, 400), (8192, 200)])
+@pytest.mark.parametrize("n,nsteps", [(4096, 400), (8192, 200), (16384, 100)])
 def test_fast_full_size_noise_runs_within_tolerance_and_bit_exact_vs_fast_oracle(n, nsteps):
-    """BASELINE.json's 4096^2 and 8192^2 grids from the bench's seeded-noise start with the source on: (a) 9 steps of the kernel the bench
+    """BASELINE.json's 4096^2, 8192^2 and 16384^2 grids from the bench's seeded-noise start with the source on: (a) 9 steps of the kernel the bench
     runs (four steps per pass + a leftover) and of the one-step kernel in FAST mode against the oracle's FAST restatement (OpenMP build), bit
     for bit; (b) `nsteps` steps FAST against EXACT (the kernels other tests hold to the exact oracle bitwise), max norm and L2 <= 1e-5."""
     import torch
@@ -232,7 +232,7 @@ def test_fast_full_size_noise_runs_within_tolerance_and_bit_exact_vs_fast_oracle
     assert bool(torch.isfinite(fpp).all())
 
 
-@pytest.mark.parametrize("n", [4096])
+@pytest.mark.parametrize("n", [4096, 8192])
 def test_fast_full_size_backward_and_imaging_vs_fast_oracle(n):
     nb, nt = 64, 6
     rng = np.random.default_rng(n + 1)

@@ -757,11 +757,11 @@ def test_image_laplacian_known_answer_and_oracle():
 
 @pytest.mark.parametrize("n", [4096, 8192, 16384])
 def test_full_size_kernels_vs_oracle_and_scale_exactly(n):
-    """BASELINE.json's full-size grids (configs 2, 4 and one GPU's worth of 5).  (a) 4096^2 and 8192^2: the one-step kernel AND the kernel
-    bench.py runs there (four steps per pass; 9 steps = two passes + one leftover one-step launch) against the ORACLE's fd_forward loop,
-    bit for bit, from a seeded noise state with the source on (the OpenMP build of oracle/fdw_oracle.c: a few seconds); 16384^2 (1 GiB per
-    field, the oracle would need 6 GiB of host arrays per run) stays kernel against kernel.  (b) the three forward kernels agree bitwise.
-    (c) linearity: doubling the source doubles the wavefield exactly (a power of two commutes with every rounding)."""
+    """BASELINE.json's full-size grids (configs 2, 4 and 5's 16384^2: 1 GiB per field).  (a) the one-step kernel AND the kernel bench.py
+    runs there (four steps per pass; 9 steps = two passes + one leftover one-step launch) against the ORACLE's fd_forward loop, bit for
+    bit, from a seeded noise state with the source on (the OpenMP build of oracle/fdw_oracle.c: seconds; at 16384^2 some 8 GiB of host
+    arrays and half a minute).  (b) the three forward kernels agree bitwise.  (c) linearity: doubling the source doubles the wavefield
+    exactly (a power of two commutes with every rounding)."""
     import torch
     dev = torch.device("cuda:0")
     nb, nt = 64, 16
@@ -793,19 +793,18 @@ def test_full_size_kernels_vs_oracle_and_scale_exactly(n):
     ctx.set_tuning(two_step=0)
     assert ctx.steps_per_pass() == 4                     # what bench.py runs at this size
     ref_p, ref_pp = run(-1, srce, False)
-    if n <= 8192:
-        orc = O.Oracle(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False, omp=True)
-        oP, oPP = orc.forward(v2[:, :n].cpu().numpy(), sx, sz, srce_h, init[0][:, :n].cpu().numpy(), init[1][:, :n].cpu().numpy(), nsteps=9)
-        del orc
-        for mode, name in ((-1, "one-step kernel"), (0, "bench kernel (four steps per pass)")):
-            p, pp = (ref_p, ref_pp) if mode == -1 else run(mode, srce, False)
-            ctx.dev_taper_finalize(p.data_ptr())         # the reference downloads the damped d_p (R:285); the lazy scheme owes it one T
-            torch.cuda.synchronize()
-            assert_bit_equal(pp[:, :n].cpu().numpy(), oPP, f"{name} vs oracle at {n}^2: PP")
-            assert_bit_equal(p[:, :n].cpu().numpy(), oP, f"{name} vs oracle at {n}^2: P")
-            assert not bool(pp[:, n:].any()) and not bool(p[:, n:].any())
-        del oP, oPP
-        ref_p, ref_pp = run(-1, srce, False)             # undamped again for the kernel-against-kernel comparison below
+    orc = O.Oracle(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False, omp=True)
+    oP, oPP = orc.forward(v2[:, :n].cpu().numpy(), sx, sz, srce_h, init[0][:, :n].cpu().numpy(), init[1][:, :n].cpu().numpy(), nsteps=9)
+    del orc
+    for mode, name in ((-1, "one-step kernel"), (0, "bench kernel (four steps per pass)")):
+        p, pp = (ref_p, ref_pp) if mode == -1 else run(mode, srce, False)
+        ctx.dev_taper_finalize(p.data_ptr())         # the reference downloads the damped d_p (R:285); the lazy scheme owes it one T
+        torch.cuda.synchronize()
+        assert_bit_equal(pp[:, :n].cpu().numpy(), oPP, f"{name} vs oracle at {n}^2: PP")
+        assert_bit_equal(p[:, :n].cpu().numpy(), oP, f"{name} vs oracle at {n}^2: P")
+        assert not bool(pp[:, n:].any()) and not bool(p[:, n:].any())
+    del oP, oPP
+    ref_p, ref_pp = run(-1, srce, False)             # undamped again for the kernel-against-kernel comparison below
     for mode in (1, 4):
         p, pp = run(mode, srce, False)
         assert torch.equal(pp, ref_pp) and torch.equal(p, ref_p), f"kernel mode {mode} differs from the one-step kernel at {n}^2"
@@ -816,7 +815,7 @@ def test_full_size_kernels_vs_oracle_and_scale_exactly(n):
     assert float(a_pp.abs().max()) > 0
 
 
-@pytest.mark.parametrize("n", [4096, 8192])
+@pytest.mark.parametrize("n", [4096, 8192, 16384])
 def test_full_size_backward_and_imaging_vs_oracle(n):
     """fd_back (source-field reconstruction + receiver step + injection + imaging, R:302-339) at BASELINE.json's full grid sizes against the
     oracle (OpenMP build), bit for bit: the kernels the library picks there by itself and the one-step kernels, 5 iterations (two pairs + one
