@@ -292,12 +292,13 @@ def test_full_size_shot_is_reproducible_and_writes_nothing_it_did_not_compute(nu
     sl.close()
 
 
-@pytest.mark.parametrize("n,world", [(8192, 2), (8192, 4), (8192, 8), (16384, 8)])
-def test_bench_geometry_slabs_equal_the_single_domain(n, world):
+@pytest.mark.parametrize("n,world,numerics", [(8192, 2, 0), (8192, 4, 0), (8192, 8, 0), (16384, 8, 0), (8192, 4, 1), (8192, 8, 1), (16384, 8, 1)])
+def test_bench_geometry_slabs_equal_the_single_domain(n, world, numerics):
     """The decompositions bench.py --gpus 2 / 4 / 8 runs (8192^2, x-slabs of 4096 / 2048 / 1024 owned rows, 8 / 12 / 16 steps per exchange, four
     steps per pass inside the slabs, strips on the side stream, lean and full tiles) and BASELINE.json's last configuration (16384^2 over eight
     ranks) with the ranks as host threads sharing this GPU and real halo copies: forward loop, hand-over, backward loop with imaging on device
-    arrays -- owned rows of both source fields, both receiver fields and the image equal the single-domain run bit for bit."""
+    arrays -- owned rows of both source fields, both receiver fields and the image equal the single-domain run bit for bit, in EXACT and in
+    FAST numerics."""
     import torch
     nb, K = 64, 40                                          # N = 8: two whole cycles of 16 + leftovers (forward: 8 steps; backward: 2 + 16 + 16 + 6)
     dev = torch.device("cuda:0")
@@ -311,7 +312,7 @@ def test_bench_geometry_slabs_equal_the_single_domain(n, world):
     torch.cuda.synchronize()
 
     def shot(comm):
-        sl = F.Slabs(8, n, n, nb, nb, K, 0.75, 10.0, 10.0, 1e-3, comm=comm, compat=False)
+        sl = F.Slabs(8, n, n, nb, nb, K, 0.75, 10.0, 10.0, 1e-3, comm=comm, compat=False, numerics=numerics)
         nfb, nrb = sl.back_buffers()
         assert (nfb, nrb) == (6, 4) and sl.nbuf == 4 and (comm is None or (sl.ksteps == {2: 8, 4: 12, 8: 16}[world] if n == 8192 else sl.ksteps % 4 == 0))
         nsrc = max(sl.nbuf, nfb)
