@@ -61,6 +61,21 @@ def test_laplacian_launch_geometries(xchunk, wz):
     assert_bit_equal(ctx.laplacian(p), O.stencil(8, 203, 777, 10.0, 10.0, p), f"xchunk={xchunk} wz={wz}")
 
 
+@pytest.mark.parametrize("n", [8192, 16384])
+def test_full_size_laplacian_vs_oracle(n):
+    """stencil_code's device work (kernel_lap, S:110-135) at the size `bench.py --workload stencil` times it and at BASELINE.json's largest
+    grid (1 GiB per field), host arrays through fdw_laplacian, against the oracle bit for bit -- in the reference's arithmetic and in FAST
+    numerics against its own restatement."""
+    rng = np.random.default_rng(n)
+    p = rng.standard_normal((n, n), dtype=np.float32)
+    for numerics in (0, 1):
+        ctx = F.FDWave(8, n, n, 64, 64, dx=10.0, dz=10.0, coef_cxx=True, numerics=numerics)
+        got = ctx.laplacian(p)
+        ctx.close()
+        assert_bit_equal(got, O.stencil(8, n, n, 10.0, 10.0, p, numerics=numerics), f"laplacian at {n}^2, numerics={numerics}")
+        assert np.abs(got).max() > 0
+
+
 def test_tables_and_extents_match_oracle(new_mod):
     ctx = mk(new_mod)
     cx, cz, tx, tz = ctx.tables()
