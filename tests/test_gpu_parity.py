@@ -667,6 +667,48 @@ def test_model_steps_fields_vs_oracle_through_lean_and_full_tiles():
         assert_bit_equal(O.mod_taper_apply(gPP[:, :nze].cpu().numpy(), nx, nz, nxb, nzb, fac, 2), wPP, f"PP nsteps={nsteps} xchunk={xchunk}")
 
 
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_full_size_modelling_steps_vs_oracle(n):
+    """The modelling loop at the size `bench.py --workload model` times it (and at 4096^2), kernels as the library picks them there (four steps
+    per pass), from random fields with the Gaussian source and the receiver line on: both fields and the gather against the oracle's
+    restatement of the sibling's loop, bit for bit -- in the sibling's arithmetic and in FAST numerics against its own restatement."""
+    import torch
+    nxb = nzb = 64
+    nx = nz = n - 2 * nxb
+    nsteps, fac = 8, 0.02
+    sx, sz, gz = n // 2 + 3, n // 3, nzb + 5
+    rng = np.random.default_rng(n + 1)
+    v2 = ((1500 + 2500 * rng.random((n, n), dtype=np.float32)) ** 2).astype(np.float32)
+    P0 = 1e-3 * rng.standard_normal((n, n), dtype=np.float32)
+    PP0 = 1e-3 * rng.standard_normal((n, n), dtype=np.float32)
+    srce = (1e-2 * rng.standard_normal(nsteps)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    for numerics in (0, 1):
+        ctx = F.FDWave(8, n, n, nxb, nzb, nsteps, fac, 10.0, 10.0, 0.001, dialect=1, numerics=numerics)
+        assert ctx.steps_per_pass() == 4
+
+        def up(a):
+            t = torch.zeros((n, ctx.pitch), device=dev)
+            t[:, :n] = torch.from_numpy(a).to(dev)
+            return t
+        p, pp, dv2, dsr = up(P0), up(PP0), up(v2), torch.from_numpy(srce).to(dev)
+        rec = torch.zeros((nsteps, nx), device=dev)
+        torch.cuda.synchronize()
+        ctx.dev_model_steps(p.data_ptr(), pp.data_ptr(), dv2.data_ptr(), dsr.data_ptr(), sx, sz, gz, rec.data_ptr(), 0, nsteps)
+        torch.cuda.synchronize()
+        O.mod_numerics(numerics)
+        try:
+            wP, wPP, wdata = O.mod_steps(8, nx, nz, nxb, nzb, 10.0, 10.0, 0.001, fac, v2, sx, sz, gz, srce,
+                                         O.mod_taper_apply(P0, nx, nz, nxb, nzb, fac, 1), O.mod_taper_apply(PP0, nx, nz, nxb, nzb, fac, 2))
+        finally:
+            O.mod_numerics(0)
+        assert_bit_equal(rec.cpu().numpy().T, wdata, f"gather at {n}^2, numerics={numerics}")
+        assert_bit_equal(O.mod_taper_apply(p[:, :n].cpu().numpy(), nx, nz, nxb, nzb, fac, 1), wP, f"P at {n}^2, numerics={numerics}")
+        assert_bit_equal(O.mod_taper_apply(pp[:, :n].cpu().numpy(), nx, nz, nxb, nzb, fac, 2), wPP, f"PP at {n}^2, numerics={numerics}")
+        assert np.abs(wdata).max() > 0
+        ctx.close()
+
+
 def test_model_dialect_guards():
     ctx = F.FDWave(8, 80, 70, 10, 10, 10, 0.02, 10.0, 10.0, 0.001, dialect=1)
     v2 = np.full((80, 70), 4e6, np.float32)
