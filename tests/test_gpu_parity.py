@@ -872,6 +872,31 @@ def test_full_size_kernels_vs_oracle_and_scale_exactly(n):
     assert float(a_pp.abs().max()) > 0
 
 
+@pytest.mark.parametrize("n", [4096, 8192])
+@pytest.mark.parametrize("numerics", [0, 1], ids=["exact", "fast"])
+def test_full_size_whole_shot_vs_oracle(n, numerics):
+    """fdw_shot -- forward loop, snapshot hand-over, backward loop with receiver injection and imaging, the kernels the library picks at
+    this size by itself (four steps / four iterations per pass with one-step leftovers: nt = 14) -- on a full-size grid against the
+    oracle's fd_forward + fd_back (OpenMP build), image and both final source-field snapshots bit for bit."""
+    nb, nt = 64, 14
+    rng = np.random.default_rng(3 * n + numerics)
+    v2 = ((1500.0 + 2500.0 * rng.random((n, n), dtype=np.float32)) ** 2).astype(np.float32)
+    srce = (O.ricker_wavelet(nt, 0.001, 30.0) + 0.25).astype(np.float32)
+    d_obs = rng.standard_normal((n - 2 * nb, nt), dtype=np.float32)
+    sx, sz, gz = n // 2 + 3, nb + 2, nb + 3
+    orc = O.Oracle(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False, omp=True, numerics=numerics)
+    oP, oPP = orc.forward(v2, sx, sz, srce)
+    want = orc.back(v2, oP, oPP, d_obs, gz)
+    del orc
+    ctx = F.FDWave(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False, numerics=numerics)
+    assert ctx.steps_per_pass() == 4
+    img, P, PP = ctx.shot(v2, sx, sz, gz, srce, d_obs, want_fields=True)
+    assert_bit_equal(PP, oPP, f"PP at {n}^2")
+    assert_bit_equal(P, oP, f"P at {n}^2")
+    assert_bit_equal(img, want, f"image at {n}^2")
+    assert np.abs(want).max() > 0
+
+
 @pytest.mark.parametrize("n", [4096, 8192, 16384])
 def test_full_size_backward_and_imaging_vs_oracle(n):
     """fd_back (source-field reconstruction + receiver step + injection + imaging, R:302-339) at BASELINE.json's full grid sizes against the
