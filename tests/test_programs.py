@@ -173,6 +173,47 @@ def test_rtm_code_program_vs_oracle_pipeline(tmp_path, with_vel_ext):
     assert np.allclose(last, img, rtol=1e-5, atol=1e-5 * np.abs(img).max())
 
 
+@pytest.mark.gpu
+def test_rtm_code_program_on_a_large_deck(tmp_path):
+    """./rtm_code where one shot fills the chip (2 980 x 2 484 extended grid, extents that are no multiples of 8: the reference's truncated
+    kernel ranges at scale): the border model drawn on the device from the rand() stream (two shots, 0.85 M draws each), the resident-model
+    shot through the four-steps-per-pass kernels the library picks from this size on (rtm_code prints nothing about it: the size is chosen
+    past fdw_api.cpp's kPipeAutoStripRows), the stack -- dir.image against the oracle's restatement of main()'s loop bit for bit, and the
+    last block of image.num (7 M lines per shot, as the reference writes it) against it as text."""
+    nx, nz, nxb, nzb, nt, ns, fsx, ds = 2900, 2404, 40, 40, 14, 2, 1400, 60
+    nxe, nze = nx + 2 * nxb, nz + 2 * nzb
+    rng = np.random.default_rng(23)
+    vp = (1500 + 2500 * np.linspace(0, 1, nz, dtype=np.float32)[None, :] + 100 * rng.standard_normal((nx, nz), dtype=np.float32)).astype(np.float32)
+    d_obs = rng.standard_normal((ns, nx, nt), dtype=np.float32)
+    (tmp_path / "models").mkdir()
+    (tmp_path / "output").mkdir()
+    vp.tofile(tmp_path / "models" / "vp.bin")
+    d_obs.tofile(tmp_path / "models" / "dobs.bin")
+    (tmp_path / "input.dat").write_text("tmpdir=./output\nvpfile=./models/vp.bin\ndatfile=./models/dobs.bin\n"
+                                        f"nz={nz}\nnx={nx}\nnt={nt}\ndz=10\ndx=10\ndt=0.001\nfpeak=25.\nns={ns}\nsz=1\nfsx={fsx}\nds={ds}\ngz=2\n"
+                                        f"nxb={nxb}\nnzb={nzb}\nrnd=1\nfac=0.75\norder=8\n")
+    r = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    orc = O.Oracle(8, nxe, nze, nxb, nzb, nt, 0.75, 10.0, 10.0, 0.001, compat=True, omp=True)
+    srce = O.ricker_wavelet(nt, 0.001, 25.0)
+    vpe = np.zeros((nxe, nze), np.float32)
+    vpe[nxb:nxb + nx, nzb:nzb + nz] = vp
+    img = np.zeros((nx, nz), np.float32)
+    for s in range(ns):
+        O.extendvel_linear(vpe, nx, nz, nxb, nzb, seed=1 if s == 0 else None)
+        v2 = (vpe * vpe).astype(np.float32)
+        P, PP = orc.forward(v2, fsx + s * ds + nxb, 1 + nzb, srce)
+        img = img + orc.back(v2, P, PP, d_obs[s], 2 + nzb)
+    got = np.fromfile(tmp_path / "output" / "dir.image", np.float32).reshape(nx, nz)
+    assert_bit_equal(got, img, "dir.image")
+    assert np.abs(got).max() > 0
+    with open(tmp_path / "image.num") as f:
+        lines = f.read().splitlines()
+    assert len(lines) == ns * (1 + nx * nz) and lines[1 + nx * nz] == "======== 1 ========"
+    last = np.array(lines[-nx * nz:], dtype=np.float64).astype(np.float32).reshape(nz, nx).T
+    assert np.allclose(last, img, rtol=1e-5, atol=1e-5 * np.abs(img).max())
+
+
 def test_bench_self_launch_without_a_gpu_fails_fast_and_clean(tmp_path):
     """The launcher of `python bench.py --gpus N` on a box WITHOUT a GPU (this container): it starts its N ranks before touching HIP itself, every
     rank finds no device and exits non-zero, the launcher reports that status without a JSON line and without waiting for a timeout.  (On a GPU
