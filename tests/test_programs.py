@@ -212,6 +212,12 @@ def test_rtm_code_program_on_a_large_deck(tmp_path):
     assert len(lines) == ns * (1 + nx * nz) and lines[1 + nx * nz] == "======== 1 ========"
     last = np.array(lines[-nx * nz:], dtype=np.float64).astype(np.float32).reshape(nz, nx).T
     assert np.allclose(last, img, rtol=1e-5, atol=1e-5 * np.abs(img).max())
+    del lines, last
+    # the same job with every shot cut into three bands of rows (ranks as host threads on this GPU, device copies for the halos)
+    r = subprocess.run([os.path.join(BIN, "rtm_code"), "./input.dat"], cwd=tmp_path, capture_output=True, text=True,
+                       env=dict(os.environ, FDW_SLABS="3", FDW_SLABS_LOCAL="1"))
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert_bit_equal(np.fromfile(tmp_path / "output" / "dir.image", np.float32).reshape(nx, nz), img, "dir.image, slabs=3")
 
 
 def test_bench_self_launch_without_a_gpu_fails_fast_and_clean(tmp_path):
