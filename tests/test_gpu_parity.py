@@ -897,6 +897,47 @@ def test_full_size_whole_shot_vs_oracle(n, numerics):
     assert np.abs(want).max() > 0
 
 
+def test_fields_beyond_2_gib_vs_oracle():
+    """The largest-size edge: a 24576 x 24576 grid, 2.25 GiB per field -- more than one buffer descriptor covers, so the four-step kernels
+    (which address a field through one) stay off and the library falls back to kernels with 64-bit row addressing.  Forward loop from noise
+    with the source near the far corner, and the backward loop with imaging from noise snapshots, against the oracle (OpenMP build) bit
+    for bit; the byte offsets of the last rows exceed 2^31."""
+    n, nb, nt = 24576, 64, 3
+    rng = np.random.default_rng(1)
+    v2 = ((1500.0 + 2500.0 * rng.random((n, n), dtype=np.float32)) ** 2).astype(np.float32)
+    p0 = 1e-3 * rng.standard_normal((n, n), dtype=np.float32)
+    pp0 = 1e-3 * rng.standard_normal((n, n), dtype=np.float32)
+    srce = (O.ricker_wavelet(nt, 0.001, 30.0) + 0.25).astype(np.float32)
+    d_obs = rng.standard_normal((n - 2 * nb, nt), dtype=np.float32)
+    sx, sz, gz = n - 200, n // 3, nb + 3
+    ctx = F.FDWave(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False)
+    assert ctx.steps_per_pass() < 4 and n * ctx.pitch * 4 > 2 ** 31
+    orc = O.Oracle(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False, omp=True)
+    P, PP = ctx.forward(v2, sx, sz, srce, p0, pp0)
+    oP, oPP = orc.forward(v2, sx, sz, srce, p0, pp0)
+    assert_bit_equal(PP, oPP, "PP on a 2.25 GiB field")
+    assert_bit_equal(P, oP, "P on a 2.25 GiB field")
+    assert np.abs(oPP[-300:]).max() > 0
+    del P, PP
+    img = ctx.back(v2, p0, pp0, d_obs, gz)
+    want = orc.back(v2, p0, pp0, d_obs, gz)
+    assert_bit_equal(img, want, "image on a 2.25 GiB field")
+    assert np.abs(want[-300:]).max() > 0
+    del img, want, orc
+    ctx.close()
+    # the same edge for the FAST instantiations and for stencil_code's Laplacian
+    fctx = F.FDWave(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False, numerics=1)
+    forc = O.Oracle(8, n, n, nb, nb, nt, 0.75, 10.0, 10.0, 0.001, compat=False, omp=True, numerics=1)
+    P, PP = fctx.forward(v2, sx, sz, srce, p0, pp0)
+    oP, oPP = forc.forward(v2, sx, sz, srce, p0, pp0)
+    assert_bit_equal(PP, oPP, "FAST PP on a 2.25 GiB field")
+    assert_bit_equal(P, oP, "FAST P on a 2.25 GiB field")
+    del P, PP, oP, oPP, forc
+    fctx.close()
+    lctx = F.FDWave(8, n, n, nb, nb, dx=10.0, dz=10.0, coef_cxx=True)
+    assert_bit_equal(lctx.laplacian(p0), O.stencil(8, n, n, 10.0, 10.0, p0), "Laplacian of a 2.25 GiB field")
+
+
 @pytest.mark.parametrize("n", [4096, 8192, 16384])
 def test_full_size_backward_and_imaging_vs_oracle(n):
     """fd_back (source-field reconstruction + receiver step + injection + imaging, R:302-339) at BASELINE.json's full grid sizes against the
