@@ -812,9 +812,10 @@ def test_image_laplacian_known_answer_and_oracle():
     assert not F.image_laplacian(one, 1.0, 1.0).any()
 
 
-@pytest.mark.parametrize("n", [4096, 8192, 16384])
+@pytest.mark.parametrize("n", [4096, 8192, 16384, 23168])
 def test_full_size_kernels_vs_oracle_and_scale_exactly(n):
-    """BASELINE.json's full-size grids (configs 2, 4 and 5's 16384^2: 1 GiB per field).  (a) the one-step kernel AND the kernel bench.py
+    """BASELINE.json's full-size grids (configs 2, 4 and 5's 16384^2: 1 GiB per field) and the largest grid the four-step kernels take
+    (23168^2: 448 KiB short of the 2 GiB one buffer descriptor covers).  (a) the one-step kernel AND the kernel bench.py
     runs there (four steps per pass; 9 steps = two passes + one leftover one-step launch) against the ORACLE's fd_forward loop, bit for
     bit, from a seeded noise state with the source on (the OpenMP build of oracle/fdw_oracle.c: seconds; at 16384^2 some 8 GiB of host
     arrays and half a minute).  (b) the three forward kernels agree bitwise.  (c) linearity: doubling the source doubles the wavefield
@@ -938,7 +939,7 @@ def test_fields_beyond_2_gib_vs_oracle():
     assert_bit_equal(lctx.laplacian(p0), O.stencil(8, n, n, 10.0, 10.0, p0), "Laplacian of a 2.25 GiB field")
 
 
-@pytest.mark.parametrize("n", [4096, 8192, 16384])
+@pytest.mark.parametrize("n", [4096, 8192, 16384, 23168])
 def test_full_size_backward_and_imaging_vs_oracle(n):
     """fd_back (source-field reconstruction + receiver step + injection + imaging, R:302-339) at BASELINE.json's full grid sizes against the
     oracle (OpenMP build), bit for bit: the kernels the library picks there by itself and the one-step kernels, 5 iterations (two pairs + one
