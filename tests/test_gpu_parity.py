@@ -293,6 +293,33 @@ def test_error_behaviour():
         ctx.forward(d["v2"][:50], d["sx"], d["sz"], np.zeros(5, np.float32))
 
 
+@pytest.mark.parametrize("compat", [True, False])
+def test_empty_loops_leave_the_fields_as_the_reference_would(compat):
+    """nt = 0 time steps: fd_forward's loop body never runs, but the function still uploads and downloads (R:252-257, R:285-287) -- the
+    arrays come back as they went in -- and fd_back's loop adds nothing to the image; one step for contrast.  Against the oracle, bit for bit,
+    through the host entry points and the device-resident shot."""
+    d = make_deck(99, 83, 17, 13, 6, compat=compat)
+    nx, nz = 99 - 34, 83 - 26
+    rng = np.random.default_rng(5)
+    p0, pp0 = [np.zeros((99, 83), np.float32) for _ in range(2)]
+    p0[17:82, 13:70] = 1e-3 * rng.standard_normal((nx, nz))      # interior only: the compat precondition on the damped strip's untouched rows
+    pp0[17:82, 13:70] = 1e-3 * rng.standard_normal((nx, nz))
+    srce = O.ricker_wavelet(6, d["dt"], 30.0)
+    d_obs = rng.standard_normal((nx, 6)).astype(np.float32)
+    im0 = rng.standard_normal((nx, nz)).astype(np.float32)
+    ctx, orc = mk(d), mko(d)
+    for n in (0, 1):
+        P, PP = ctx.forward(d["v2"], d["sx"], d["sz"], srce, p0, pp0, nsteps=n)
+        oP, oPP = orc.forward(d["v2"], d["sx"], d["sz"], srce, p0, pp0, nsteps=n)
+        assert_bit_equal(P, oP, f"P after {n} steps")
+        assert_bit_equal(PP, oPP, f"PP after {n} steps")
+        img = ctx.back(d["v2"], p0, pp0, d_obs, d["gz"], imloc=im0, nsteps=n)
+        assert_bit_equal(img, orc.back(d["v2"], p0, pp0, d_obs, d["gz"], imloc=im0, nsteps=n), f"image after {n} iterations")
+        if n == 0:
+            assert_bit_equal(img, im0, "image after no iteration")
+            assert_bit_equal(PP, pp0, "PP after no step")
+
+
 def test_reference_named_wrappers():
     d = make_deck(96, 80, 16, 16, 20)
     srce = O.ricker_wavelet(20, d["dt"], 30.0)
