@@ -1,8 +1,25 @@
 import os
 import sys
 
-import numpy as np
-import pytest
+
+def _host_threads():
+    """Threads this process may really use (affinity mask, cgroup CPU quota), at most 16 -- the CPU share of a one-GPU box, whose kernel shows
+    hundreds of hardware threads.  The OpenMP build of the oracle (and torch's own pool) would otherwise start one thread per hardware thread
+    it sees, and the fine-grained parallel loops of a small grid then crawl (the six-shot new_mod test: 137 s instead of 3 s)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(_host_threads()))      # before numpy / torch / liborc_omp.so are loaded
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 if ROOT not in sys.path:

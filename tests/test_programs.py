@@ -349,13 +349,19 @@ def test_rtm_code_on_the_reference_new_mod_deck_all_six_shots(tmp_path):
     assert r.returncode == 0, r.stderr + r.stdout
     assert "## nz = 195, nx = 315, nt = 1700 " in r.stdout and "** source 6, at (307,0) " in r.stdout, r.stdout
     got = np.fromfile(tmp_path / "output" / "dir.image", np.float32).reshape(nx, nz)
-    orc = O.Oracle(8, 415, 295, nxb, nzb, nt, 0.75, 10.0, 10.0, 0.001, compat=True, omp=True)
     srce = O.ricker_wavelet(nt, 0.001, 20.0)
-    img = np.zeros((nx, nz), np.float32)
-    for s in range(ns):
+
+    def oracle_shot(s):      # one oracle state per shot (no shared state in fdw_oracle.c's RTM passes; ctypes releases the GIL): the six shots side by side
+        orc = O.Oracle(8, 415, 295, nxb, nzb, nt, 0.75, 10.0, 10.0, 0.001, compat=True)
         v2 = (vel[s] * vel[s]).astype(np.float32)
         P, PP = orc.forward(v2, fsx + s * ds + nxb, nzb, srce)
-        imloc = orc.back(v2, P, PP, dobs[s], nzb)
+        return orc.back(v2, P, PP, dobs[s], nzb)
+
+    import concurrent.futures
+    with concurrent.futures.ThreadPoolExecutor(max_workers=ns) as pool:
+        imlocs = list(pool.map(oracle_shot, range(ns)))
+    img = np.zeros((nx, nz), np.float32)
+    for imloc in imlocs:                                   # stacked in shot order, as main() does (R:522-528)
         assert np.abs(imloc).max() > 0
         img = img + imloc
     assert_bit_equal(got, img, "dir.image of the six-shot new_mod deck")
