@@ -766,7 +766,9 @@ static int stepn_impl(fdw_ctx* c, int mode, const float* d_p, const float* d_pp,
     // 1056x8192 371 at 43 (355 at 63, 340 at 33)
     // end of round 2 (scripts/probe_pipe.py, PIPE_SHAPE): 4128x8192 (half of the bench grid) 584 at 83, 592 at 123, 609 at 143, 601 at 173;
     // 2144x8192 538 at 83 (499 at 53, 521 at 103)
-    int xchunk = c->xchunk2 > 0 ? c->xchunk2 : (strip_rows >= 1000000 ? 253 : (strip_rows >= 250000 ? 173 : (strip_rows >= 120000 ? 143 : (strip_rows >= 60000 ? 83 : 43))));
+    // end of round 3 (same probe, FAST numerics): 4128x8192 677 at 143, 710 at 173, 700 at 83 -- the memory-bound FAST kernel prefers the longer chunk there
+    const bool fastnum = c->prm.numerics == FDW_NUMERICS_FAST;
+    int xchunk = c->xchunk2 > 0 ? c->xchunk2 : (strip_rows >= 1000000 ? 253 : (strip_rows >= 250000 ? 173 : (strip_rows >= 120000 ? (fastnum ? 173 : 143) : (strip_rows >= 60000 ? 83 : 43))));
     if (mode == FDW_MODE_BACK4 && c->xchunk2 <= 0) {
         // the eight-wave kernel holds two workgroups per CU (512 at a time): longer chunks than the forward kernel's at the same grid size
         // (scripts/probe_slabs_c.py, us per iteration by chunk length 43 / 83 / 123 / 173: 8192 rows 363 / 309 / 289 / 277; 4160 rows 192 / 172 / 157 / 162;
